@@ -1,0 +1,468 @@
+"""circom_compat_amd -- MI355X-native Groth16 (BN254) proving path for Circom circuits.
+
+Host-side mirror (Python harness flavour) of the reference's surface for the proving path:
+
+    reference (ark-circom 0.5)                              here
+    ------------------------------------------------------  -----------------------------------
+    read_zkey(reader) -> (ProvingKey, ConstraintMatrices)   read_zkey(path | bytes)
+        src/zkey.rs:53-60
+    R1CSFile::new(reader), R1CS::from(file)                 R1CSFile(path | bytes), R1CS.from_file
+        src/circom/r1cs_reader.rs:26-39,54-146
+    CircomCircuit{r1cs, witness}.get_public_inputs()        CircomCircuit(...).get_public_inputs()
+        src/circom/circuit.rs:12-26
+    CircomReduction::witness_map_from_matrices              CircomReduction.witness_map_from_matrices
+        src/circom/qap.rs:23-88
+    Groth16::<Bn254,CircomReduction>::                      Groth16.create_proof_with_reduction_and_matrices
+        create_proof_with_reduction_and_matrices            (same argument order)
+        benches/groth16.rs:52-60, src/zkey.rs:903-911
+    Groth16::prove(&pk, circuit, rng)  src/zkey.rs:866      Groth16.prove(pk, matrices, circuit, rng)
+
+All arithmetic happens in libg16_amd.so (hand-written HIP for gfx950) behind the C ABI of
+include/g16_amd.h.  Witness generation (circom WASM), Ethereum helpers and the arkworks
+ConstraintSystem layer are out of scope.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import random
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _binding as B
+from ._binding import G16Error, SerializationError, SynthesisError  # noqa: F401
+
+__all__ = ["read_zkey", "R1CSFile", "R1CS", "CircomCircuit", "CircomReduction", "Groth16",
+           "Prover", "ProvingKey", "VerifyingKey", "ConstraintMatrices", "Proof", "G16Error",
+           "SynthesisError", "SerializationError", "fr_from_ints", "fr_to_ints", "read_wtns"]
+
+FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def fr_from_ints(values: Sequence[int], lib: Optional[B.Library] = None) -> np.ndarray:
+    """canonical ints -> (n, 4) uint64 Montgomery limbs (the in-memory form of ark_bn254::Fr)."""
+    lib = lib or B.load()
+    raw = b"".join((int(v) % FR_MODULUS).to_bytes(32, "little") for v in values)
+    src = np.frombuffer(raw, dtype=np.uint8)
+    out = np.empty((len(values), 4), dtype=np.uint64)
+    lib.check(lib.g16_fr_from_canonical(_np_ptr(src), _np_ptr(out), len(values)), loader=True)
+    return out
+
+
+def fr_to_ints(limbs: np.ndarray, lib: Optional[B.Library] = None) -> List[int]:
+    lib = lib or B.load()
+    limbs = np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty(limbs.shape[0] * 32, dtype=np.uint8)
+    lib.check(lib.g16_fr_to_canonical(_np_ptr(limbs), _np_ptr(out), limbs.shape[0]), loader=True)
+    b = out.tobytes()
+    return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+
+def _as_fr(x, lib) -> np.ndarray:
+    """accept Montgomery (n,4) uint64 arrays or sequences of canonical ints"""
+    if isinstance(x, np.ndarray) and x.dtype == np.uint64:
+        return np.ascontiguousarray(x).reshape(-1, 4)
+    return fr_from_ints(list(x), lib)
+
+
+class Csr:
+    """row-major sparse rows of (coeff, index): ConstraintMatrices::{a,b} (src/zkey.rs:165-194)"""
+
+    def __init__(self, row_ptr, col, coeff):
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+        self.col = np.ascontiguousarray(col, dtype=np.uint32)
+        self.coeff = np.ascontiguousarray(coeff, dtype=np.uint64).reshape(-1, 4)
+        assert self.col.shape[0] == self.coeff.shape[0] == int(self.row_ptr[-1])
+
+    @staticmethod
+    def from_c(c: B.Csr, nrows: int) -> "Csr":
+        nnz = int(c.nnz)
+        rp = np.ctypeslib.as_array(c.row_ptr, shape=(nrows + 1,)).copy()
+        col = np.ctypeslib.as_array(c.col, shape=(max(nnz, 1),))[:nnz].copy()
+        co = np.ctypeslib.as_array(c.coeff, shape=(max(nnz, 1) * 4,))[:nnz * 4].copy()
+        return Csr(rp, col, co)
+
+    @staticmethod
+    def from_rows(rows, lib=None) -> "Csr":
+        """rows: list of lists of (coeff_int, index)"""
+        rp = [0]
+        col, vals = [], []
+        for row in rows:
+            for cf, idx in row:
+                col.append(idx)
+                vals.append(cf)
+            rp.append(len(col))
+        return Csr(rp, col, fr_from_ints(vals, lib) if vals else np.zeros((0, 4), np.uint64))
+
+    def to_c(self) -> B.Csr:
+        c = B.Csr()
+        c.row_ptr = self.row_ptr.ctypes.data_as(C.POINTER(C.c_uint32))
+        c.col = self.col.ctypes.data_as(C.POINTER(C.c_uint32))
+        c.coeff = self.coeff.ctypes.data_as(C.POINTER(C.c_uint64))
+        c.nnz = self.col.shape[0]
+        return c
+
+    @property
+    def num_rows(self):
+        return self.row_ptr.shape[0] - 1
+
+
+class ConstraintMatrices:
+    """ark_relations::r1cs::ConstraintMatrices as read_zkey fills it (src/zkey.rs:179-193)."""
+
+    def __init__(self, num_instance_variables, num_witness_variables, num_constraints, a: Csr,
+                 b: Csr):
+        self.num_instance_variables = num_instance_variables
+        self.num_witness_variables = num_witness_variables
+        self.num_constraints = num_constraints
+        self.a, self.b = a, b
+        self.a_num_non_zero = a.col.shape[0]
+        self.b_num_non_zero = b.col.shape[0]
+        self.c_num_non_zero = 0  # src/zkey.rs:188-192: c is empty
+
+
+class VerifyingKey:
+    def __init__(self, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1):
+        self.alpha_g1, self.beta_g2, self.gamma_g2, self.delta_g2 = alpha_g1, beta_g2, gamma_g2, delta_g2
+        self.gamma_abc_g1 = gamma_abc_g1  # (p+1, 64) uint8
+
+
+class ProvingKey:
+    """ark_groth16::ProvingKey<Bn254> in packed form (points: Montgomery x|y bytes)."""
+
+    def __init__(self, n_vars, n_public, domain_size, vk: VerifyingKey, beta_g1, delta_g1, a_query,
+                 b_g1_query, b_g2_query, l_query, h_query, keepalive=None):
+        self.n_vars, self.n_public, self.domain_size = n_vars, n_public, domain_size
+        self.vk, self.beta_g1, self.delta_g1 = vk, beta_g1, delta_g1
+        self.a_query, self.b_g1_query, self.b_g2_query = a_query, b_g1_query, b_g2_query
+        self.l_query, self.h_query = l_query, h_query
+        self._keepalive = keepalive
+        self._prover = None
+
+    def to_c(self) -> B.KeyDesc:
+        k = B.KeyDesc()
+        k.n_vars, k.n_public, k.domain_size = self.n_vars, self.n_public, self.domain_size
+        for name in ("a_query", "b_g1_query", "b_g2_query", "l_query", "h_query"):
+            arr = getattr(self, name)
+            setattr(k, name, arr.ctypes.data if arr is not None else None)
+        C.memmove(k.alpha_g1, bytes(self.vk.alpha_g1), 64)
+        C.memmove(k.beta_g1, bytes(self.beta_g1), 64)
+        C.memmove(k.delta_g1, bytes(self.delta_g1), 64)
+        C.memmove(k.beta_g2, bytes(self.vk.beta_g2), 128)
+        C.memmove(k.delta_g2, bytes(self.vk.delta_g2), 128)
+        return k
+
+
+class _Handle:
+    def __init__(self, lib, ptr, closer):
+        self.lib, self.ptr, self._closer = lib, ptr, closer
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._closer(self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+
+def read_zkey(src, lib: Optional[B.Library] = None) -> Tuple[ProvingKey, ConstraintMatrices]:
+    """read_zkey (reference src/zkey.rs:53-60): snarkjs .zkey -> (ProvingKey, ConstraintMatrices)."""
+    lib = lib or B.load()
+    h = C.c_void_p()
+    if isinstance(src, (bytes, bytearray, memoryview)):
+        buf = np.frombuffer(bytes(src), dtype=np.uint8)
+        lib.check(lib.g16_zkey_open_mem(_np_ptr(buf), buf.shape[0], C.byref(h)), loader=True)
+    else:
+        lib.check(lib.g16_zkey_open(os.fsencode(src), C.byref(h)), loader=True)
+    handle = _Handle(lib, h, lib.g16_zkey_close)
+    hdr = B.ZkeyHeader()
+    lib.check(lib.g16_zkey_header_get(h, C.byref(hdr)), loader=True)
+    kd = B.KeyDesc()
+    lib.check(lib.g16_zkey_key(h, C.byref(kd)), loader=True)
+    N, p, n = hdr.n_vars, hdr.n_public, hdr.domain_size
+
+    def view(ptr, count, width):
+        if count == 0:
+            return np.zeros((0, width), dtype=np.uint8)
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * width,))
+        return arr.reshape(count, width)
+
+    cnt = C.c_uint32()
+    icp = lib.g16_zkey_ic(h, C.byref(cnt))
+    vk = VerifyingKey(bytes(hdr.alpha_g1), bytes(hdr.beta_g2), bytes(hdr.gamma_g2),
+                      bytes(hdr.delta_g2), view(icp, cnt.value, 64).copy())
+    pk = ProvingKey(N, p, n, vk, bytes(hdr.beta_g1), bytes(hdr.delta_g1),
+                    view(kd.a_query, N, 64), view(kd.b_g1_query, N, 64),
+                    view(kd.b_g2_query, N, 128), view(kd.l_query, N - p - 1, 64),
+                    view(kd.h_query, n, 64), keepalive=handle)
+    m = B.Matrices()
+    lib.check(lib.g16_zkey_matrices(h, C.byref(m)), loader=True)
+    mats = ConstraintMatrices(m.num_instance_variables, m.num_witness_variables, m.num_constraints,
+                              Csr.from_c(m.a, m.num_constraints), Csr.from_c(m.b, m.num_constraints))
+    return pk, mats
+
+
+class R1CSFile:
+    """R1CSFile::new (reference src/circom/r1cs_reader.rs:54-146)."""
+
+    def __init__(self, src, lib: Optional[B.Library] = None):
+        lib = lib or B.load()
+        h = C.c_void_p()
+        if isinstance(src, (bytes, bytearray, memoryview)):
+            buf = np.frombuffer(bytes(src), dtype=np.uint8)
+            lib.check(lib.g16_r1cs_open_mem(_np_ptr(buf), buf.shape[0], C.byref(h)), loader=True)
+        else:
+            lib.check(lib.g16_r1cs_open(os.fsencode(src), C.byref(h)), loader=True)
+        self._handle = _Handle(lib, h, lib.g16_r1cs_close)
+        hdr = B.R1csHeader()
+        lib.check(lib.g16_r1cs_header_get(h, C.byref(hdr)), loader=True)
+        self.version = hdr.version
+        self.header = hdr
+        a, b, c = B.Csr(), B.Csr(), B.Csr()
+        lib.check(lib.g16_r1cs_matrices(h, C.byref(a), C.byref(b), C.byref(c)), loader=True)
+        nc = hdr.n_constraints
+        self.a, self.b, self.c = Csr.from_c(a, nc), Csr.from_c(b, nc), Csr.from_c(c, nc)
+        cnt = C.c_uint32()
+        wm = lib.g16_r1cs_wire_mapping(h, C.byref(cnt))
+        self.wire_mapping = list(np.ctypeslib.as_array(C.cast(wm, C.POINTER(C.c_uint64)),
+                                                       shape=(cnt.value,)))
+
+
+class R1CS:
+    """R1CS::from(R1CSFile) (reference src/circom/r1cs_reader.rs:26-39)."""
+
+    def __init__(self, file: R1CSFile):
+        h = file.header
+        self.num_inputs = 1 + h.n_pub_in + h.n_pub_out
+        self.num_variables = h.n_wires
+        self.num_aux = self.num_variables - self.num_inputs
+        self.a, self.b, self.c = file.a, file.b, file.c
+        self.num_constraints = h.n_constraints
+        self.wire_mapping: Optional[List[int]] = [int(x) for x in file.wire_mapping]
+
+    @staticmethod
+    def from_file(src, lib=None) -> "R1CS":
+        return R1CS(R1CSFile(src, lib))
+
+    def matrices(self) -> ConstraintMatrices:
+        """A and B in the ConstraintMatrices orientation the prover consumes."""
+        return ConstraintMatrices(self.num_inputs, self.num_aux, self.num_constraints, self.a, self.b)
+
+
+def read_wtns(src, lib: Optional[B.Library] = None) -> np.ndarray:
+    """snarkjs .wtns -> (n, 4) uint64 Montgomery witness."""
+    lib = lib or B.load()
+    out = C.c_void_p()
+    n = C.c_uint32()
+    if isinstance(src, (bytes, bytearray, memoryview)):
+        buf = np.frombuffer(bytes(src), dtype=np.uint8)
+        lib.check(lib.g16_wtns_read_mem(_np_ptr(buf), buf.shape[0], C.byref(out), C.byref(n)),
+                  loader=True)
+    else:
+        lib.check(lib.g16_wtns_read(os.fsencode(src), C.byref(out), C.byref(n)), loader=True)
+    arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(n.value * 4,)).copy()
+    lib.g16_free(out)
+    return arr.reshape(-1, 4)
+
+
+class CircomCircuit:
+    """CircomCircuit{r1cs, witness} (reference src/circom/circuit.rs:12-26).  The witness comes from
+    outside (circom's WASM generator is out of scope): ints or Montgomery limbs."""
+
+    def __init__(self, r1cs: R1CS, witness=None):
+        self.r1cs = r1cs
+        self.witness = witness
+
+    def get_public_inputs(self):
+        if self.witness is None:
+            return None
+        w = self.witness
+        m = self.r1cs.wire_mapping
+        if m is None:
+            return [w[i] for i in range(1, self.r1cs.num_inputs)]
+        return [w[m[i]] for i in range(1, self.r1cs.num_inputs)]
+
+
+class Proof:
+    """ark_groth16::Proof<Bn254>{a, b, c} as packed affine bytes (Montgomery LE, zero = infinity)."""
+
+    def __init__(self, raw: bytes):
+        assert len(raw) == B.G16_PROOF_BYTES
+        self.raw = bytes(raw)
+        self.a, self.b, self.c = self.raw[:64], self.raw[64:192], self.raw[192:]
+
+    def __eq__(self, o):
+        return isinstance(o, Proof) and o.raw == self.raw
+
+    def __repr__(self):
+        return f"Proof({self.raw.hex()[:32]}...)"
+
+
+class Prover:
+    """Device-resident (pk, matrices): the state create_proof_with_reduction_and_matrices borrows
+    on every call in the reference, uploaded and precomputed once here (g16_ctx_create)."""
+
+    def __init__(self, pk: Optional[ProvingKey], matrices: ConstraintMatrices, device=0, rank=0,
+                 world=1, window_bits=0, planes=0, lib: Optional[B.Library] = None,
+                 n_vars: Optional[int] = None):
+        self.lib = lib or B.load()
+        self.matrices = matrices
+        self.pk = pk
+        if pk is None:  # witness-map-only context (R1CSToQAP use)
+            if n_vars is None:
+                n_vars = matrices.num_instance_variables + matrices.num_witness_variables - 1
+            need = matrices.num_constraints + matrices.num_instance_variables
+            dom = 1
+            while dom < need:
+                dom <<= 1
+            kd = B.KeyDesc()
+            kd.n_vars, kd.n_public, kd.domain_size = n_vars, matrices.num_instance_variables - 1, dom
+        else:
+            kd = pk.to_c()
+        self.n_vars = kd.n_vars
+        self.domain_size = kd.domain_size
+        opt = B.Options()
+        opt.device, opt.rank, opt.world = device, rank, world
+        opt.window_bits, opt.planes = window_bits, planes
+        self.rank, self.world = rank, world
+        a, b = matrices.a.to_c(), matrices.b.to_c()
+        ctx = C.c_void_p()
+        st = self.lib.g16_ctx_create(C.byref(kd), C.byref(a), C.byref(b), matrices.num_constraints,
+                                     C.byref(opt), C.byref(ctx))
+        self.lib.check(st, None)
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.g16_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    __del__ = close
+
+    # -- CircomReduction::witness_map_from_matrices
+    def witness_map(self, full_assignment) -> np.ndarray:
+        w = _as_fr(full_assignment, self.lib)
+        h = np.empty((self.domain_size, 4), dtype=np.uint64)
+        self.lib.check(self.lib.g16_witness_map(self.ctx, _np_ptr(w), w.shape[0], _np_ptr(h)), self.ctx)
+        return h
+
+    def msm_g1(self, which: int, scalars) -> bytes:
+        s = _as_fr(scalars, self.lib)
+        out = np.empty(64, dtype=np.uint8)
+        self.lib.check(self.lib.g16_msm_g1(self.ctx, which, _np_ptr(s), s.shape[0], _np_ptr(out)), self.ctx)
+        return out.tobytes()
+
+    def msm_g2(self, scalars) -> bytes:
+        s = _as_fr(scalars, self.lib)
+        out = np.empty(128, dtype=np.uint8)
+        self.lib.check(self.lib.g16_msm_g2(self.ctx, _np_ptr(s), s.shape[0], _np_ptr(out)), self.ctx)
+        return out.tobytes()
+
+    def prove(self, r, s, full_assignment) -> Proof:
+        w = _as_fr(full_assignment, self.lib)
+        rs = _as_fr([r, s], self.lib) if not isinstance(r, np.ndarray) else np.stack([r, s])
+        out = np.empty(B.G16_PROOF_BYTES, dtype=np.uint8)
+        self.lib.check(self.lib.g16_prove(self.ctx, _np_ptr(rs[0:1]), _np_ptr(rs[1:2]), _np_ptr(w),
+                                          w.shape[0], _np_ptr(out)), self.ctx)
+        return Proof(out.tobytes())
+
+    def prove_dev(self, r, s, w_dev_ptr: int) -> Proof:
+        """witness already resident in HBM (device pointer to n_vars x 32 bytes)"""
+        rs = _as_fr([r, s], self.lib) if not isinstance(r, np.ndarray) else np.stack([r, s])
+        out = np.empty(B.G16_PROOF_BYTES, dtype=np.uint8)
+        self.lib.check(self.lib.g16_prove_dev(self.ctx, _np_ptr(rs[0:1]), _np_ptr(rs[1:2]),
+                                              C.c_void_p(w_dev_ptr), self.n_vars, _np_ptr(out)), self.ctx)
+        return Proof(out.tobytes())
+
+    def prove_partial(self, full_assignment=None, w_dev_ptr: Optional[int] = None) -> bytes:
+        out = np.empty(B.G16_PARTIAL_BYTES, dtype=np.uint8)
+        if w_dev_ptr is not None:
+            st = self.lib.g16_prove_partial_dev(self.ctx, C.c_void_p(w_dev_ptr), self.n_vars, _np_ptr(out))
+        else:
+            w = _as_fr(full_assignment, self.lib)
+            st = self.lib.g16_prove_partial(self.ctx, _np_ptr(w), w.shape[0], _np_ptr(out))
+        self.lib.check(st, self.ctx)
+        return out.tobytes()
+
+    def prove_finish(self, r, s, partials: bytes) -> Proof:
+        rs = _as_fr([r, s], self.lib) if not isinstance(r, np.ndarray) else np.stack([r, s])
+        world = len(partials) // B.G16_PARTIAL_BYTES
+        buf = np.frombuffer(partials, dtype=np.uint8)
+        out = np.empty(B.G16_PROOF_BYTES, dtype=np.uint8)
+        self.lib.check(self.lib.g16_prove_finish(self.ctx, _np_ptr(rs[0:1]), _np_ptr(rs[1:2]),
+                                                 _np_ptr(buf), world, _np_ptr(out)), self.ctx)
+        return Proof(out.tobytes())
+
+    def witness_buffer(self) -> int:
+        return int(self.lib.g16_witness_buffer(self.ctx) or 0)
+
+    def set_profiling(self, on: bool):
+        self.lib.check(self.lib.g16_set_profiling(self.ctx, 1 if on else 0), self.ctx)
+
+    def stage_times(self):
+        ms = (C.c_float * B.G16_N_STAGES)()
+        cnt = (C.c_uint32 * B.G16_N_STAGES)()
+        self.lib.check(self.lib.g16_stage_times(self.ctx, ms, cnt), self.ctx)
+        return {self.lib.g16_stage_name(i).decode(): (float(ms[i]), int(cnt[i]))
+                for i in range(B.G16_N_STAGES)}
+
+    def info(self):
+        out = (C.c_uint32 * 16)()
+        self.lib.check(self.lib.g16_ctx_info(self.ctx, out), self.ctx)
+        keys = ["c_w", "W_w", "planes_w", "D_w", "c_h", "W_h", "planes_h", "D_h", "domain_size",
+                "log_n", "shard_w", "shard_h"]
+        return dict(zip(keys, list(out)))
+
+
+class CircomReduction:
+    """R1CSToQAP impl used for circom/snarkjs keys (reference src/circom/qap.rs:12-106)."""
+
+    @staticmethod
+    def witness_map_from_matrices(matrices: ConstraintMatrices, num_inputs: int,
+                                  num_constraints: int, full_assignment, lib=None, device=0):
+        if num_inputs != matrices.num_instance_variables or num_constraints != matrices.num_constraints:
+            raise G16Error(B.G16_ERR_INVALID, "num_inputs/num_constraints do not match the matrices")
+        pr = getattr(matrices, "_wm_prover", None)
+        if pr is None:
+            n_vars = len(full_assignment)
+            pr = Prover(None, matrices, device=device, lib=lib, n_vars=n_vars)
+            matrices._wm_prover = pr
+        return pr.witness_map(full_assignment)
+
+
+class Groth16:
+    """Groth16::<Bn254, CircomReduction> entry points of the proving path."""
+
+    @staticmethod
+    def _prover(pk: ProvingKey, matrices: ConstraintMatrices, **kw) -> Prover:
+        if pk._prover is None or pk._prover.matrices is not matrices:
+            pk._prover = Prover(pk, matrices, **kw)
+        return pk._prover
+
+    @staticmethod
+    def create_proof_with_reduction_and_matrices(pk: ProvingKey, r, s, matrices: ConstraintMatrices,
+                                                 num_inputs: int, num_constraints: int,
+                                                 full_assignment, **kw) -> Proof:
+        """Argument order of reference benches/groth16.rs:52-60 / src/zkey.rs:903-911."""
+        if num_inputs != matrices.num_instance_variables or num_constraints != matrices.num_constraints:
+            raise G16Error(B.G16_ERR_INVALID, "num_inputs/num_constraints do not match the matrices")
+        return Groth16._prover(pk, matrices, **kw).prove(r, s, full_assignment)
+
+    @staticmethod
+    def prove(pk: ProvingKey, matrices: ConstraintMatrices, circuit: CircomCircuit, rng=None, **kw) -> Proof:
+        """SNARK::prove(&pk, circuit, rng) (reference src/zkey.rs:866): r, s <- rng, then the matrices
+        entry (rebuilding a ConstraintSystem per proof is the serial host work this path avoids)."""
+        rng = rng or random.SystemRandom()
+        r = rng.randrange(FR_MODULUS)
+        s = rng.randrange(FR_MODULUS)
+        w = circuit.witness
+        if circuit.r1cs.wire_mapping is not None and not isinstance(w, np.ndarray):
+            pass  # circom witnesses are already in wire order; the mapping only relabels signals
+        return Groth16.create_proof_with_reduction_and_matrices(
+            pk, r, s, matrices, matrices.num_instance_variables, matrices.num_constraints, w, **kw)

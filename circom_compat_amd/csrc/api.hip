@@ -1,0 +1,492 @@
+// api.hip -- the C ABI declared in include/g16_amd.h: context (device-resident key, matrices,
+// tables, workspaces) and the per-proof drivers.  Host-side orchestration only; all arithmetic
+// runs in the HIP kernels of ntt.hip / witness_map.hip / msm_*.hip / finalize.hip.
+#include "../../include/g16_amd.h"
+
+#include <mutex>
+
+#include "finalize.h"
+#include "msm.h"
+#include "witness_map.h"
+
+using namespace g16;
+
+namespace {
+std::mutex g_err_mu;
+std::string g_create_error;
+}  // namespace
+
+struct g16_ctx {
+  int device = 0, rank = 0, world = 1;
+  uint32_t N = 0, p = 0, n = 0, m = 0, num_inputs = 0;
+  bool has_key = false;  // false: witness-map-only context (a_query == NULL at create)
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  WitnessMap wm;
+  // shard of the assignment-index space [0, N-1) (entry i <-> w[1+i]) and of [0, n) for H
+  uint32_t w_lo = 0, w_hi = 0, h_lo = 0, h_hi = 0;
+  uint32_t l_idx_min = 0;  // entries below this local index have no L point (public inputs)
+  MsmConfig cfg_w, cfg_h;
+  MsmSort sort_w, sort_h;
+  MsmPoints<Fq> ptsA, ptsB1, ptsL, ptsH;
+  MsmPoints<Fq2> ptsB2;
+  MsmWork<Fq> work1;
+  MsmWork<Fq2> work2;
+
+  DevBuf<Fr> w_dev, h_dev, rs_dev;
+  DevBuf<KeyHeaderDev> key_dev;
+  DevBuf<ProofSums> sums_dev;
+  DevBuf<uint8_t> out_dev;  // proof (256) | partial (384) | gathered partials
+  DevBuf<G1Affine> aff1;
+  DevBuf<G2Affine> aff2;
+
+  StageTimer timer;
+  float st_ms[ST_COUNT] = {0};
+  uint32_t st_cnt[ST_COUNT] = {0};
+};
+
+namespace {
+
+g16_status fail(g16_ctx* ctx, g16_status code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  else {
+    std::lock_guard<std::mutex> g(g_err_mu);
+    g_create_error = msg;
+  }
+  return code;
+}
+
+template <class Fn>
+g16_status guarded(g16_ctx* ctx, Fn fn) {
+  try {
+    if (ctx) G16_HIP(hipSetDevice(ctx->device));
+    return fn();
+  } catch (const HipError& e) {
+    return fail(ctx, G16_ERR_HIP, e.what());
+  } catch (const std::bad_alloc&) {
+    return fail(ctx, G16_ERR_INTERNAL, "host allocation failed");
+  } catch (const std::exception& e) {
+    const bool dom = std::string(e.what()).find("PolynomialDegreeTooLarge") != std::string::npos;
+    return fail(ctx, dom ? G16_ERR_DOMAIN_TOO_LARGE : G16_ERR_INTERNAL, e.what());
+  }
+}
+
+void shard(uint32_t len, int rank, int world, uint32_t* lo, uint32_t* hi) {
+  *lo = (uint32_t)((uint64_t)len * rank / world);
+  *hi = (uint32_t)((uint64_t)len * (rank + 1) / world);
+}
+
+// choose the largest number of planes that fits the memory still free on the device
+MsmConfig fit_config(size_t len, int c_over, int planes_over, size_t bytes_per_point_all_queries,
+                     size_t reserve) {
+  MsmConfig cfg = msm_make_config(len, c_over, planes_over);
+  if (planes_over > 0) return cfg;
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return cfg;
+  const size_t budget = fr > reserve ? (size_t)((fr - reserve) * 0.7) : 0;
+  int pn = cfg.Pn;
+  while (pn > 1 && (size_t)pn * len * bytes_per_point_all_queries > budget) --pn;
+  if (pn != cfg.Pn) cfg = msm_make_config(len, c_over, pn);
+  return cfg;
+}
+
+void collect_times(g16_ctx* c) {
+  if (c->timer.enabled) c->timer.collect(c->st_ms, c->st_cnt);
+}
+
+// MSMs of one proof on this ctx's shard; results left in sums_dev
+void run_msms(g16_ctx* c, const Fr* w_dev) {
+  hipStream_t s = c->stream;
+  StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
+  ProofSums* S = c->sums_dev.p;
+  // witness map first (H needs h); the witness-only sort does not depend on it
+  int id = tm ? tm->begin(ST_WITNESS_NTT, s) : -1;
+  c->wm.run(w_dev, c->h_dev.p, s);
+  if (tm) tm->end(id, s);
+
+  id = tm ? tm->begin(ST_MSM_SORT, s) : -1;
+  c->sort_w.run(w_dev + 1 + c->w_lo, c->w_hi - c->w_lo, /*mont=*/true, s);
+  if (tm) tm->end(id, s);
+  msm_run<Fq>(c->sort_w, c->ptsA, 0, c->work1, &S->A, s, tm);
+  msm_run<Fq>(c->sort_w, c->ptsB1, 0, c->work1, &S->B1, s, tm);
+  msm_run<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, &S->L, s, tm);
+  msm_run<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, &S->B2, s, tm);
+
+  id = tm ? tm->begin(ST_MSM_SORT, s) : -1;
+  c->sort_h.run(c->h_dev.p + c->h_lo, c->h_hi - c->h_lo, /*mont=*/true, s);
+  if (tm) tm->end(id, s);
+  msm_run<Fq>(c->sort_h, c->ptsH, 0, c->work1, &S->H, s, tm);
+}
+
+g16_status check_w(g16_ctx* c, size_t n_vars) {
+  if (n_vars != c->N) return fail(c, G16_ERR_INVALID, "witness length != n_vars of the key");
+  return G16_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* g16_last_error(const g16_ctx* ctx) {
+  if (ctx) return ctx->err.c_str();
+  std::lock_guard<std::mutex> g(g_err_mu);
+  static thread_local std::string copy;
+  copy = g_create_error;
+  return copy.c_str();
+}
+
+g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
+                          uint32_t num_constraints, const g16_options* opt, g16_ctx** out) {
+  if (!key || !a || !b || !out) return fail(nullptr, G16_ERR_INVALID, "null argument");
+  *out = nullptr;
+  g16_options o{};
+  if (opt) o = *opt;
+  if (o.world <= 0) o.world = 1;
+  if (o.rank < 0 || o.rank >= o.world) return fail(nullptr, G16_ERR_INVALID, "bad rank/world");
+  if (key->n_vars < key->n_public + 1) return fail(nullptr, G16_ERR_INVALID, "n_vars < n_public+1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, G16_ERR_NO_DEVICE,
+                "no HIP device visible: this library has no CPU fallback");
+  if (o.device < 0 || o.device >= ndev) return fail(nullptr, G16_ERR_INVALID, "bad device ordinal");
+
+  g16_ctx* c = new (std::nothrow) g16_ctx();
+  if (!c) return fail(nullptr, G16_ERR_INTERNAL, "host allocation failed");
+  c->device = o.device;
+  c->rank = o.rank;
+  c->world = o.world;
+  g16_status st = guarded(c, [&]() -> g16_status {
+    G16_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipStream_t s = c->stream;
+    c->N = key->n_vars;
+    c->p = key->n_public;
+    c->num_inputs = c->p + 1;
+    c->m = num_constraints;
+    CsrHost A{a->row_ptr, a->col, (const Fr*)a->coeff, (size_t)a->nnz};
+    CsrHost B{b->row_ptr, b->col, (const Fr*)b->coeff, (size_t)b->nnz};
+    c->wm.init(A, B, c->m, c->num_inputs);
+    c->n = c->wm.n;
+    if (key->domain_size != c->n)
+      throw std::runtime_error("key domain_size does not match num_constraints + num_inputs");
+
+    const uint32_t len_w = c->N - 1;
+    shard(len_w, c->rank, c->world, &c->w_lo, &c->w_hi);
+    shard(c->n, c->rank, c->world, &c->h_lo, &c->h_hi);
+    const uint32_t lw = c->w_hi - c->w_lo, lh = c->h_hi - c->h_lo;
+
+    c->w_dev.alloc(c->N);
+    c->h_dev.alloc(c->n);
+    c->has_key = key->a_query != nullptr;
+    if (!c->has_key) {
+      G16_HIP(hipStreamSynchronize(s));
+      return G16_OK;
+    }
+    if (!key->b_g1_query || !key->b_g2_query || !key->h_query || (!key->l_query && c->N > c->p + 1))
+      throw std::runtime_error("key descriptor has null query arrays");
+    c->rs_dev.alloc(2);
+    c->key_dev.alloc(1);
+    c->sums_dev.alloc(1);
+    c->out_dev.alloc(G16_PROOF_BYTES + G16_PARTIAL_BYTES * (size_t)(c->world + 1));
+    c->aff1.alloc(1);
+    c->aff2.alloc(1);
+
+    // MSM configurations: the four witness queries share one sort, hence one (c, W, planes)
+    const size_t reserve = (size_t)3 << 30;
+    c->cfg_w = fit_config(lw ? lw : 1, o.window_bits, o.planes, 64 * 3 + 128, reserve);
+    c->sort_w.init(lw, c->cfg_w);
+    c->ptsA.init((const G1Affine*)key->a_query + 1 + c->w_lo, lw, c->cfg_w, s);
+    c->ptsB1.init((const G1Affine*)key->b_g1_query + 1 + c->w_lo, lw, c->cfg_w, s);
+    c->ptsB2.init((const G2Affine*)key->b_g2_query + 1 + c->w_lo, lw, c->cfg_w, s);
+    {
+      // L pairs l_query[j] with w[num_inputs + j], i.e. entry index i = p + j
+      const uint32_t first = c->w_lo > c->p ? c->w_lo : c->p;  // first global entry with an L point
+      const uint32_t cnt = c->w_hi > first ? c->w_hi - first : 0;
+      c->l_idx_min = first - c->w_lo;
+      c->ptsL.init((const G1Affine*)key->l_query + (first - c->p), cnt, c->cfg_w, s);
+    }
+    c->cfg_h = fit_config(lh ? lh : 1, o.window_bits, o.planes, 64, reserve);
+    c->sort_h.init(lh, c->cfg_h);
+    c->ptsH.init((const G1Affine*)key->h_query + c->h_lo, lh, c->cfg_h, s);
+
+    // one workspace per curve, large enough for either sort
+    {
+      const uint32_t nc_w = ceil_div(c->cfg_w.B, MSM_RED_CHUNK) * c->cfg_w.D;
+      const uint32_t nc_h = ceil_div(c->cfg_h.B, MSM_RED_CHUNK) * c->cfg_h.D;
+      const uint32_t mt = c->sort_w.max_tasks > c->sort_h.max_tasks ? c->sort_w.max_tasks
+                                                                    : c->sort_h.max_tasks;
+      const int dmax = c->cfg_w.D > c->cfg_h.D ? c->cfg_w.D : c->cfg_h.D;
+      c->work1.init(mt, nc_w > nc_h ? nc_w : nc_h, dmax);
+      c->work2.init(c->sort_w.max_tasks, nc_w, c->cfg_w.D);
+    }
+
+    KeyHeaderDev kh;
+    memcpy(&kh.alpha1, key->alpha_g1, 64);
+    memcpy(&kh.beta1, key->beta_g1, 64);
+    memcpy(&kh.delta1, key->delta_g1, 64);
+    memcpy(&kh.a0, key->a_query, 64);
+    memcpy(&kh.b1_0, key->b_g1_query, 64);
+    memcpy(&kh.beta2, key->beta_g2, 128);
+    memcpy(&kh.delta2, key->delta_g2, 128);
+    memcpy(&kh.b2_0, key->b_g2_query, 128);
+    G16_HIP(hipMemcpyAsync(c->key_dev.p, &kh, sizeof kh, hipMemcpyHostToDevice, s));
+    G16_HIP(hipStreamSynchronize(s));
+    return G16_OK;
+  });
+  if (st != G16_OK) {
+    {
+      std::lock_guard<std::mutex> g(g_err_mu);
+      g_create_error = c->err;
+    }
+    g16_ctx_destroy(c);
+    return st;
+  }
+  *out = c;
+  return G16_OK;
+}
+
+void g16_ctx_destroy(g16_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+g16_status g16_witness_map(g16_ctx* c, const uint64_t* w, size_t n_vars, uint64_t* h_out) {
+  if (!c || !w || !h_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+  return guarded(c, [&]() -> g16_status {
+    hipStream_t s = c->stream;
+    G16_HIP(hipMemcpyAsync(c->w_dev.p, w, (size_t)c->N * 32, hipMemcpyHostToDevice, s));
+    c->wm.run(c->w_dev.p, c->h_dev.p, s);
+    G16_HIP(hipMemcpyAsync(h_out, c->h_dev.p, (size_t)c->n * 32, hipMemcpyDeviceToHost, s));
+    G16_HIP(hipStreamSynchronize(s));
+    return G16_OK;
+  });
+}
+
+static g16_status msm_common(g16_ctx* c, int which, bool g2, const uint64_t* scalars, size_t len,
+                             uint8_t* out) {
+  if (!c || !scalars || !out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
+  if (c->world != 1) return fail(c, G16_ERR_INVALID, "g16_msm_* needs a world == 1 ctx");
+  return guarded(c, [&]() -> g16_status {
+    hipStream_t s = c->stream;
+    MsmSort* sort = &c->sort_w;
+    uint32_t idx_min = 0;
+    const MsmPoints<Fq>* P1 = nullptr;
+    size_t maxlen = 0;
+    Fr* stage = c->w_dev.p;  // scalar staging: reuse the witness / h buffers
+    if (g2) {
+      maxlen = c->ptsB2.count;
+    } else if (which == G16_QUERY_A) {
+      P1 = &c->ptsA;
+      maxlen = P1->count;
+    } else if (which == G16_QUERY_B1) {
+      P1 = &c->ptsB1;
+      maxlen = P1->count;
+    } else if (which == G16_QUERY_L) {
+      P1 = &c->ptsL;
+      maxlen = P1->count;
+    } else if (which == G16_QUERY_H) {
+      P1 = &c->ptsH;
+      maxlen = P1->count;
+      sort = &c->sort_h;
+      stage = c->h_dev.p;
+    } else {
+      return fail(c, G16_ERR_INVALID, "unknown query id");
+    }
+    if (len > maxlen) return fail(c, G16_ERR_INVALID, "more scalars than resident points");
+    G16_HIP(hipMemcpyAsync(stage, scalars, len * 32, hipMemcpyHostToDevice, s));
+    sort->run(stage, (uint32_t)len, true, s);
+    (void)idx_min;
+    if (g2) {
+      msm_run<Fq2>(*sort, c->ptsB2, 0, c->work2, &c->sums_dev.p->B2, s, nullptr);
+    } else {
+      // for L the entry index is already the l_query index here (scalars pair with l_query[i])
+      msm_run<Fq>(*sort, *P1, 0, c->work1, &c->sums_dev.p->A, s, nullptr);
+    }
+    sums_to_partial(c->sums_dev.p, c->out_dev.p, s);  // A -> bytes [0,64), B2 -> [128,256)
+    G16_HIP(hipMemcpyAsync(out, c->out_dev.p + (g2 ? 128 : 0), g2 ? 128 : 64,
+                           hipMemcpyDeviceToHost, s));
+    G16_HIP(hipStreamSynchronize(s));
+    return G16_OK;
+  });
+}
+
+g16_status g16_msm_g1(g16_ctx* c, int which, const uint64_t* scalars, size_t len, uint8_t out[64]) {
+  return msm_common(c, which, false, scalars, len, out);
+}
+g16_status g16_msm_g2(g16_ctx* c, const uint64_t* scalars, size_t len, uint8_t out[128]) {
+  return msm_common(c, 0, true, scalars, len, out);
+}
+
+g16_status g16_prove_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], const void* w_dev,
+                         size_t n_vars, uint8_t proof_out[G16_PROOF_BYTES]) {
+  if (!c || !r || !s_ || !w_dev || !proof_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
+  if (c->world != 1) return fail(c, G16_ERR_INVALID, "g16_prove needs world == 1; use partial/finish");
+  if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+  return guarded(c, [&]() -> g16_status {
+    hipStream_t s = c->stream;
+    uint64_t rs[8];
+    memcpy(rs, r, 32);
+    memcpy(rs + 4, s_, 32);
+    G16_HIP(hipMemcpyAsync(c->rs_dev.p, rs, 64, hipMemcpyHostToDevice, s));
+    run_msms(c, (const Fr*)w_dev);
+    int id = c->timer.enabled ? c->timer.begin(ST_FINALIZE, s) : -1;
+    finalize_proof(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->out_dev.p, s);
+    c->timer.end(id, s);
+    G16_HIP(hipMemcpyAsync(proof_out, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
+    G16_HIP(hipStreamSynchronize(s));
+    collect_times(c);
+    return G16_OK;
+  });
+}
+
+g16_status g16_prove(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], const uint64_t* w,
+                     size_t n_vars, uint8_t proof_out[G16_PROOF_BYTES]) {
+  if (!c || !w) return fail(c, G16_ERR_INVALID, "null argument");
+  if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+  g16_status st = guarded(c, [&]() -> g16_status {
+    G16_HIP(hipMemcpyAsync(c->w_dev.p, w, (size_t)c->N * 32, hipMemcpyHostToDevice, c->stream));
+    return G16_OK;
+  });
+  if (st != G16_OK) return st;
+  return g16_prove_dev(c, r, s_, c->w_dev.p, n_vars, proof_out);
+}
+
+g16_status g16_prove_partial_dev(g16_ctx* c, const void* w_dev, size_t n_vars,
+                                 uint8_t partial_out[G16_PARTIAL_BYTES]) {
+  if (!c || !w_dev || !partial_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
+  if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+  return guarded(c, [&]() -> g16_status {
+    hipStream_t s = c->stream;
+    run_msms(c, (const Fr*)w_dev);
+    uint8_t* part = c->out_dev.p + G16_PROOF_BYTES;
+    sums_to_partial(c->sums_dev.p, part, s);
+    G16_HIP(hipMemcpyAsync(partial_out, part, G16_PARTIAL_BYTES, hipMemcpyDeviceToHost, s));
+    G16_HIP(hipStreamSynchronize(s));
+    collect_times(c);
+    return G16_OK;
+  });
+}
+
+g16_status g16_prove_partial(g16_ctx* c, const uint64_t* w, size_t n_vars,
+                             uint8_t partial_out[G16_PARTIAL_BYTES]) {
+  if (!c || !w) return fail(c, G16_ERR_INVALID, "null argument");
+  if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+  g16_status st = guarded(c, [&]() -> g16_status {
+    G16_HIP(hipMemcpyAsync(c->w_dev.p, w, (size_t)c->N * 32, hipMemcpyHostToDevice, c->stream));
+    return G16_OK;
+  });
+  if (st != G16_OK) return st;
+  return g16_prove_partial_dev(c, c->w_dev.p, n_vars, partial_out);
+}
+
+g16_status g16_prove_finish(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4],
+                            const uint8_t* partials, int world,
+                            uint8_t proof_out[G16_PROOF_BYTES]) {
+  if (!c || !r || !s_ || !partials || !proof_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
+  if (world != c->world) return fail(c, G16_ERR_INVALID, "world does not match the ctx");
+  return guarded(c, [&]() -> g16_status {
+    hipStream_t s = c->stream;
+    uint64_t rs[8];
+    memcpy(rs, r, 32);
+    memcpy(rs + 4, s_, 32);
+    G16_HIP(hipMemcpyAsync(c->rs_dev.p, rs, 64, hipMemcpyHostToDevice, s));
+    uint8_t* gathered = c->out_dev.p + G16_PROOF_BYTES + G16_PARTIAL_BYTES;
+    G16_HIP(hipMemcpyAsync(gathered, partials, (size_t)world * G16_PARTIAL_BYTES,
+                           hipMemcpyHostToDevice, s));
+    partials_to_sums(gathered, world, c->sums_dev.p, s);
+    finalize_proof(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->out_dev.p, s);
+    G16_HIP(hipMemcpyAsync(proof_out, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
+    G16_HIP(hipStreamSynchronize(s));
+    return G16_OK;
+  });
+}
+
+g16_status g16_set_profiling(g16_ctx* c, int enabled) {
+  if (!c) return G16_ERR_INVALID;
+  c->timer.enabled = enabled != 0;
+  for (int i = 0; i < ST_COUNT; ++i) {
+    c->st_ms[i] = 0.f;
+    c->st_cnt[i] = 0;
+  }
+  return G16_OK;
+}
+
+g16_status g16_stage_times(g16_ctx* c, float ms[G16_N_STAGES], uint32_t launches[G16_N_STAGES]) {
+  if (!c || !ms || !launches) return G16_ERR_INVALID;
+  static_assert(G16_N_STAGES == ST_COUNT, "stage table out of sync with the header");
+  for (int i = 0; i < ST_COUNT; ++i) {
+    ms[i] = c->st_ms[i];
+    launches[i] = c->st_cnt[i];
+    c->st_ms[i] = 0.f;
+    c->st_cnt[i] = 0;
+  }
+  return G16_OK;
+}
+
+const char* g16_stage_name(int stage) {
+  static const char* names[ST_COUNT] = {"witness_spmv",  "witness_map",        "witness_pointwise",
+                                        "msm_sort",      "msm_accumulate_g1",  "msm_accumulate_g2",
+                                        "msm_reduce",    "finalize"};
+  return (stage >= 0 && stage < ST_COUNT) ? names[stage] : "?";
+}
+
+g16_status g16_ctx_info(const g16_ctx* c, uint32_t out[16]) {
+  if (!c || !out) return G16_ERR_INVALID;
+  memset(out, 0, 16 * sizeof(uint32_t));
+  out[0] = c->cfg_w.c; out[1] = c->cfg_w.W; out[2] = c->cfg_w.Pn; out[3] = c->cfg_w.D;
+  out[4] = c->cfg_h.c; out[5] = c->cfg_h.W; out[6] = c->cfg_h.Pn; out[7] = c->cfg_h.D;
+  out[8] = c->n;
+  out[9] = (uint32_t)c->wm.plan.k;
+  out[10] = c->w_hi - c->w_lo;
+  out[11] = c->h_hi - c->h_lo;
+  return G16_OK;
+}
+
+void* g16_witness_buffer(g16_ctx* c) { return c ? (void*)c->w_dev.p : nullptr; }
+
+g16_status g16_debug_ntt(int device, uint64_t* data, int log_n, int inverse, int algo) {
+  if (!data || log_n < 0) return fail(nullptr, G16_ERR_INVALID, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, G16_ERR_NO_DEVICE, "no HIP device visible");
+  try {
+    G16_HIP(hipSetDevice(device));
+    NttPlan plan;
+    plan.build(log_n);
+    const size_t n = plan.n;
+    DevBuf<Fr> a, b;
+    a.alloc(n);
+    b.alloc(n);
+    G16_HIP(hipMemcpy(a.p, data, n * 32, hipMemcpyHostToDevice));
+    Fr* res = a.p;
+    if (algo == 0) {
+      ntt_dif(plan, a.p, n, 1, inverse != 0, inverse ? NTT_FUSE_SCALE : NTT_FUSE_NONE, nullptr);
+      bitrev_copy(a.p, b.p, log_n, nullptr);
+      res = b.p;
+    } else {
+      if (inverse) return fail(nullptr, G16_ERR_INVALID, "algo 1 (DIT) is forward-only");
+      bitrev_copy(a.p, b.p, log_n, nullptr);
+      ntt_dit(plan, b.p, n, 1, false, nullptr);
+      res = b.p;
+    }
+    G16_HIP(hipDeviceSynchronize());
+    G16_HIP(hipMemcpy(data, res, n * 32, hipMemcpyDeviceToHost));
+    return G16_OK;
+  } catch (const HipError& e) {
+    return fail(nullptr, G16_ERR_HIP, e.what());
+  } catch (const std::exception& e) {
+    return fail(nullptr, G16_ERR_INTERNAL, e.what());
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// msm.h -- BN254 variable-base multi-scalar multiplication (Pippenger bucket method) on gfx950.
+//
+// Replaces ark-ec VariableBaseMSM::msm_bigint as invoked (through ark-groth16
+// create_proof_with_assignment) for the A, B1, L, H queries in G1 and the B2 query in G2; the
+// reference call sites are src/zkey.rs:903-911 and benches/groth16.rs:52-60, the query arrays are
+// the ones read_zkey produces (src/zkey.rs:103-133).
+//
+// MI355X-first design:
+//  * signed c-bit digits (2^(c-1) buckets per bucket set), zero digits skipped;
+//  * the 288 GB of HBM is spent on precomputed multiples 2^(c*D*j) * P_i stored as extra affine
+//    "planes": window w = j*D + d reads plane j and feeds bucket set d, so with full
+//    precomputation (D = 1) ALL windows share one bucket set -- one bucket reduction per MSM and
+//    no 254-step doubling chain at the end;
+//  * one counting sort of (bucket, point) pairs per *scalar vector*; A, B1, B2 and L reuse the same
+//    sorted list because they share the witness as scalars;
+//  * bucket filling is split into tasks of <= MSM_CHUNK entries so that skewed witnesses (most
+//    circom wires are 0/1) cannot serialise on one hot bucket; partial sums are then combined by
+//    a thread (few partials) or a whole workgroup (many partials) per bucket.
+#pragma once
+#include "common.h"
+
+namespace g16 {
+
+constexpr int MSM_CHUNK = 256;      // max entries one thread accumulates
+constexpr int MSM_SMALL_MULTI = 32; // buckets with <= this many partials are combined by one thread
+constexpr int MSM_RED_CHUNK = 8;    // buckets per thread in the weighted bucket reduction
+constexpr uint32_t MSM_IDX_BITS = 26;
+constexpr uint32_t MSM_IDX_MASK = (1u << MSM_IDX_BITS) - 1u;
+
+struct MsmConfig {
+  int c = 0;       // window bits
+  int W = 0;       // number of windows, W*c >= 255
+  int Pn = 1;      // stored multiples (planes) per point
+  int D = 0;       // bucket sets = ceil(W / Pn)
+  uint32_t B = 0;  // buckets per set = 2^(c-1)
+  uint32_t nb() const { return (uint32_t)D * B; }
+};
+
+// c_override / planes_override <= 0 selects the defaults for `len` scalars.
+MsmConfig msm_make_config(size_t len, int c_override, int planes_override);
+
+struct MsmTask {
+  uint32_t g;  // global bucket id d*B + bucket
+  uint32_t k;  // chunk number inside the bucket
+};
+
+// Sorted (bucket -> entries) view of one scalar vector.  entry = idx | plane << 26 | neg << 31.
+struct MsmSort {
+  MsmConfig cfg;
+  uint32_t cap = 0, len = 0, max_tasks = 0;
+  DevBuf<U256> canon;
+  DevBuf<uint32_t> count, offset, cursor, ntask_off, entries, multi_s, multi_l, meta, scan_tmp;
+  DevBuf<MsmTask> tasks;
+
+  void init(uint32_t capacity, const MsmConfig& cfg);
+  // scalars: `n` field elements (Montgomery Fr when mont, else canonical U256) in device memory
+  void run(const void* scalars, uint32_t n, bool mont, hipStream_t stream);
+  size_t device_bytes() const;
+};
+
+template <class F>
+struct MsmPoints {
+  MsmConfig cfg;
+  uint32_t count = 0;
+  DevBuf<Affine<F>> pts;  // [Pn][count]
+  // uploads `count` affine points (packed Montgomery x|y, all-zero = infinity) and fills the planes
+  void init(const Affine<F>* host_points, uint32_t count, const MsmConfig& cfg, hipStream_t stream);
+  // same, from points already in device memory (key generator)
+  void init_from_device(const Affine<F>* dev_points, uint32_t count, const MsmConfig& cfg,
+                        hipStream_t stream);
+};
+
+template <class F>
+struct MsmWork {
+  DevBuf<XYZZ<F>> partial;  // one per task
+  DevBuf<XYZZ<F>> contrib;  // one per reduction chunk
+  DevBuf<XYZZ<F>> bsum;     // intermediate tree level
+  DevBuf<XYZZ<F>> wsum;     // one per bucket set
+  // sized for the larger of several sorts that will share this workspace
+  void init(uint32_t max_tasks, uint32_t n_contrib, int max_sets);
+};
+
+// out_dev[0] = sum_i scalar_i * P_{i - idx_min} over the entries of `s` with idx >= idx_min.
+template <class F>
+void msm_run(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min, MsmWork<F>& work,
+             XYZZ<F>* out_dev, hipStream_t stream, StageTimer* tm = nullptr);
+
+// Fr Montgomery -> canonical (ark-ff into_bigint), n elements
+void fr_to_canonical(const Fr* in, U256* out, uint32_t n, hipStream_t stream);
+
+
+}  // namespace g16

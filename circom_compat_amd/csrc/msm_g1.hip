@@ -1,0 +1,8 @@
+// msm_g1.hip -- G1 (Fq) instantiation of the MSM kernels (A, B1, L, H queries).
+#include "msm_curve.inc.h"
+namespace g16 {
+template struct MsmPoints<Fq>;
+template struct MsmWork<Fq>;
+template void msm_run<Fq>(const MsmSort&, const MsmPoints<Fq>&, uint32_t, MsmWork<Fq>&, XYZZ<Fq>*,
+                          hipStream_t, StageTimer*);
+}  // namespace g16

@@ -1,0 +1,8 @@
+// msm_g2.hip -- G2 (Fq2) instantiation of the MSM kernels (B2 query).
+#include "msm_curve.inc.h"
+namespace g16 {
+template struct MsmPoints<Fq2>;
+template struct MsmWork<Fq2>;
+template void msm_run<Fq2>(const MsmSort&, const MsmPoints<Fq2>&, uint32_t, MsmWork<Fq2>&,
+                           XYZZ<Fq2>*, hipStream_t, StageTimer*);
+}  // namespace g16

@@ -1,0 +1,246 @@
+// msm_sort.hip -- digit decomposition + counting sort of (bucket, point) pairs for the MSM.
+//
+// Stands in for ark-ec's make_digits / per-window bucket fill loop (VariableBaseMSM::msm_bigint,
+// reached from the call sites cited in msm.h).  One run per *scalar vector*: the witness-based
+// queries A, B1, B2, L share one sorted list, the H query has its own.
+#include "msm.h"
+
+namespace g16 {
+
+MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
+  MsmConfig cfg;
+  int lg = 0;
+  while (((size_t)1 << (lg + 1)) <= len) ++lg;
+  int c = lg - 2;
+  if (c < 3) c = 3;
+  if (c > 21) c = 21;
+  if (c_override > 0) c = c_override;
+  if (c < 2) c = 2;
+  if (c > 24) c = 24;
+  cfg.c = c;
+  cfg.W = (255 + c - 1) / c;
+  int pn = planes_override > 0 ? planes_override : cfg.W;
+  if (pn > cfg.W) pn = cfg.W;
+  if (pn > 32) pn = 32;  // 5 plane bits in an entry
+  cfg.D = (cfg.W + pn - 1) / pn;
+  cfg.Pn = (cfg.W + cfg.D - 1) / cfg.D;
+  cfg.B = 1u << (c - 1);
+  return cfg;
+}
+
+namespace {
+
+__global__ void __launch_bounds__(256) k_fr_to_canonical(const Fr* in, U256* out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = in[i].to_canonical();
+}
+
+// Walks the signed c-bit digits of canonical scalar i; emit(g, entry) for every non-zero digit.
+template <class Emit>
+__device__ __forceinline__ void for_each_digit(const U256* canon, uint32_t i, int c, int W, int D,
+                                               uint32_t B, Emit emit) {
+  const uint32_t* sp = canon[i].v;
+  const uint32_t mask = (1u << c) - 1u;
+  const uint32_t half = 1u << (c - 1);
+  uint32_t carry = 0;
+  for (int w = 0; w < W; ++w) {
+    const int bit = w * c;
+    const int limb = bit >> 5, sh = bit & 31;
+    uint32_t raw = 0;
+    if (limb < 8) {
+      raw = sp[limb] >> sh;
+      if (sh + c > 32 && limb + 1 < 8) raw |= sp[limb + 1] << (32 - sh);
+      raw &= mask;
+    }
+    raw += carry;
+    uint32_t mag, neg;
+    if (raw > half) {
+      mag = (1u << c) - raw;
+      neg = 1;
+      carry = 1;
+    } else {
+      mag = raw;
+      neg = 0;
+      carry = 0;
+    }
+    if (mag) {
+      const uint32_t d = (uint32_t)(w % D), j = (uint32_t)(w / D);
+      emit(d * B + (mag - 1), i | (j << MSM_IDX_BITS) | (neg << 31));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_digit_hist(const U256* canon, uint32_t n, int c, int W,
+                                                    int D, uint32_t B, uint32_t* count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for_each_digit(canon, i, c, W, D, B, [&](uint32_t g, uint32_t) { atomicAdd(&count[g], 1u); });
+}
+
+__global__ void __launch_bounds__(256) k_digit_scatter(const U256* canon, uint32_t n, int c, int W,
+                                                       int D, uint32_t B, uint32_t* cursor,
+                                                       uint32_t* entries) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for_each_digit(canon, i, c, W, D, B, [&](uint32_t g, uint32_t e) {
+    const uint32_t pos = atomicAdd(&cursor[g], 1u);
+    entries[pos] = e;
+  });
+}
+
+// ---- exclusive scan of L u32 values (optionally of ceil(x / MSM_CHUNK)), 1024 values per block
+constexpr int SCAN_T = 256, SCAN_V = 4, SCAN_TILE = SCAN_T * SCAN_V;
+
+__device__ __forceinline__ uint32_t scan_xform(uint32_t x, int mode) {
+  return mode ? (x + MSM_CHUNK - 1) / MSM_CHUNK : x;
+}
+
+// block-wide exclusive scan of one value per thread; returns the exclusive prefix, total in *tot
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* sh, uint32_t* tot) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int off = 1; off < SCAN_T; off <<= 1) {
+    uint32_t x = (t >= off) ? sh[t - off] : 0;
+    __syncthreads();
+    sh[t] += x;
+    __syncthreads();
+  }
+  const uint32_t incl = sh[t];
+  *tot = sh[SCAN_T - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_block_sums(const uint32_t* in, uint32_t L, int mode,
+                                                            uint32_t* bsum) {
+  __shared__ uint32_t sh[SCAN_T];
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_V;
+  uint32_t s = 0;
+  for (int v = 0; v < SCAN_V; ++v)
+    if (base + v < L) s += scan_xform(in[base + v], mode);
+  uint32_t tot;
+  (void)block_excl_scan(s, sh, &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_top(uint32_t* bsum, uint32_t nblk, uint32_t* total) {
+  __shared__ uint32_t sh[SCAN_T];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nblk; base += SCAN_T) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nblk ? bsum[i] : 0;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(v, sh, &tot);
+    if (i < nblk) bsum[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_apply(const uint32_t* in, uint32_t L, int mode,
+                                                       const uint32_t* bsum, uint32_t* out,
+                                                       uint32_t* out2) {
+  __shared__ uint32_t sh[SCAN_T];
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_V;
+  uint32_t x[SCAN_V];
+  uint32_t s = 0;
+  for (int v = 0; v < SCAN_V; ++v) {
+    x[v] = (base + v < L) ? scan_xform(in[base + v], mode) : 0;
+    s += x[v];
+  }
+  uint32_t tot;
+  uint32_t run = block_excl_scan(s, sh, &tot) + bsum[blockIdx.x];
+  for (int v = 0; v < SCAN_V; ++v) {
+    if (base + v < L) {
+      out[base + v] = run;
+      if (out2) out2[base + v] = run;
+    }
+    run += x[v];
+  }
+}
+
+// out[0..L) = exclusive scan, out[L] = total.  tmp needs ceil(L/1024) words.
+void scan_exclusive(const uint32_t* in, uint32_t L, int mode, uint32_t* out, uint32_t* out2,
+                    uint32_t* tmp, hipStream_t s) {
+  const uint32_t nblk = ceil_div(L, SCAN_TILE);
+  G16_LAUNCH(k_scan_block_sums, nblk, SCAN_T, 0, s, in, L, mode, tmp);
+  G16_LAUNCH(k_scan_top, 1, SCAN_T, 0, s, tmp, nblk, out + L);
+  G16_LAUNCH(k_scan_apply, nblk, SCAN_T, 0, s, in, L, mode, (const uint32_t*)tmp, out, out2);
+}
+
+__global__ void __launch_bounds__(256) k_task_fill(const uint32_t* ntask_off, uint32_t nb,
+                                                   MsmTask* tasks, uint32_t* multi_s,
+                                                   uint32_t* multi_l, uint32_t* meta) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  const uint32_t first = ntask_off[g];
+  const uint32_t nt = ntask_off[g + 1] - first;
+  for (uint32_t k = 0; k < nt; ++k) tasks[first + k] = MsmTask{g, k};
+  if (nt > (uint32_t)MSM_SMALL_MULTI) {
+    multi_l[atomicAdd(&meta[1], 1u)] = g;
+  } else if (nt > 1) {
+    multi_s[atomicAdd(&meta[0], 1u)] = g;
+  }
+}
+
+}  // namespace
+
+void fr_to_canonical(const Fr* in, U256* out, uint32_t n, hipStream_t stream) {
+  if (n) G16_LAUNCH(k_fr_to_canonical, ceil_div(n, 256), 256, 0, stream, in, out, n);
+}
+
+void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
+  cfg = c;
+  cap = capacity;
+  if (capacity > MSM_IDX_MASK) throw std::runtime_error("MSM slice too large (2^26 points max)");
+  const uint32_t nb = cfg.nb();
+  const uint64_t M = (uint64_t)cap * cfg.W;
+  if (M >= ((uint64_t)1 << 32)) throw std::runtime_error("MSM entry count exceeds 2^32");
+  canon.alloc(cap ? cap : 1);
+  count.alloc((size_t)nb + 1);
+  offset.alloc((size_t)nb + 1);
+  cursor.alloc((size_t)nb + 1);
+  ntask_off.alloc((size_t)nb + 1);
+  entries.alloc(M ? M : 1);
+  const uint64_t nonempty = M < nb ? M : nb;
+  max_tasks = (uint32_t)(M / MSM_CHUNK + nonempty + 1);
+  tasks.alloc(max_tasks);
+  multi_s.alloc((size_t)(M / (MSM_CHUNK + 1)) + 2);
+  multi_l.alloc((size_t)(M / ((uint64_t)MSM_CHUNK * MSM_SMALL_MULTI + 1)) + 2);
+  meta.alloc(4);
+  scan_tmp.alloc(ceil_div((uint64_t)nb + 1, SCAN_TILE) + 1);
+}
+
+size_t MsmSort::device_bytes() const {
+  return canon.bytes() + count.bytes() + offset.bytes() + cursor.bytes() + ntask_off.bytes() +
+         entries.bytes() + tasks.bytes() + multi_s.bytes() + multi_l.bytes();
+}
+
+void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
+  if (n > cap) throw std::runtime_error("MsmSort::run: more scalars than capacity");
+  len = n;
+  const uint32_t nb = cfg.nb();
+  const U256* cs;
+  if (mont) {
+    fr_to_canonical((const Fr*)scalars, canon.p, n, s);
+    cs = canon.p;
+  } else {
+    cs = (const U256*)scalars;
+  }
+  G16_HIP(hipMemsetAsync(count.p, 0, ((size_t)nb + 1) * 4, s));
+  G16_HIP(hipMemsetAsync(meta.p, 0, 16, s));
+  if (n)
+    G16_LAUNCH(k_digit_hist, ceil_div(n, 256), 256, 0, s, cs, n, cfg.c, cfg.W, cfg.D, cfg.B,
+               count.p);
+  scan_exclusive(count.p, nb, 0, offset.p, cursor.p, scan_tmp.p, s);
+  if (n)
+    G16_LAUNCH(k_digit_scatter, ceil_div(n, 256), 256, 0, s, cs, n, cfg.c, cfg.W, cfg.D, cfg.B,
+               cursor.p, entries.p);
+  scan_exclusive(count.p, nb, 1, ntask_off.p, nullptr, scan_tmp.p, s);
+  G16_LAUNCH(k_task_fill, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)ntask_off.p, nb, tasks.p,
+             multi_s.p, multi_l.p, meta.p);
+}
+
+}  // namespace g16

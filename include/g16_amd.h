@@ -1,0 +1,146 @@
+/* g16_amd.h -- C ABI of the MI355X-native Groth16 (BN254) proving path for Circom circuits.
+ *
+ * Drop-in boundary for the proving path of arkworks-rs/circom-compat (ark-circom 0.5.0).  The
+ * reference has no FFI of its own; the seam is the call
+ *   Groth16::<Bn254, CircomReduction>::create_proof_with_reduction_and_matrices(
+ *       &pk, r, s, &matrices, num_inputs, num_constraints, &full_assignment)
+ * (reference benches/groth16.rs:52-60, src/zkey.rs:903-911) plus the loaders that feed it
+ * (read_zkey, src/zkey.rs:53-60; R1CSFile::new, src/circom/r1cs_reader.rs:54-146).  Each entry
+ * point below names the reference interface it replaces.  INTEGRATION.md shows the Rust
+ * `extern "C"` binding a maintainer would add on the ark-circom side.
+ *
+ * Conventions
+ *  - Field elements are 4 x u64 little-endian limbs in MONTGOMERY form (R = 2^256): exactly the
+ *    in-memory form of ark_bn254::{Fr,Fq} (`x.0.0`) and the on-disk form of zkey points
+ *    (src/zkey.rs:327-332).  "Fr" arguments (witness, r, s, CSR coefficients, h) are Montgomery.
+ *  - G1 affine = x|y (64 bytes), G2 affine = x.c0|x.c1|y.c0|y.c1 (128 bytes), all-zero = point
+ *    at infinity: the packed form deserialize_g1/g2 decode (src/zkey.rs:340-360).
+ *  - Every function returns a g16_status; no exceptions cross the boundary; the caller owns all
+ *    buffers; a ctx is not re-entrant (one call in flight per ctx, several ctxs allowed).
+ *  - There is NO CPU fallback: without a usable HIP device g16_ctx_create fails with
+ *    G16_ERR_NO_DEVICE.
+ */
+#ifndef G16_AMD_H
+#define G16_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int g16_status;
+enum {
+  G16_OK = 0,
+  G16_ERR_INVALID = 1,          /* bad argument / size mismatch                                  */
+  G16_ERR_DOMAIN_TOO_LARGE = 2, /* SynthesisError::PolynomialDegreeTooLarge (qap.rs:31,66)       */
+  G16_ERR_HIP = 3,              /* HIP runtime error, see g16_last_error                         */
+  G16_ERR_NO_DEVICE = 4,        /* no gfx950 device visible: the product path refuses to run     */
+  G16_ERR_IO = 5,               /* SerializationError / io error in a loader                     */
+  G16_ERR_INTERNAL = 6
+};
+
+typedef struct g16_ctx g16_ctx;
+
+/* Row-major sparse matrix = ConstraintMatrices::{a,b} (Vec<Vec<(Fr, usize)>>, src/zkey.rs:165-194)
+ * flattened to CSR.  coeff: nnz x 4 u64, Montgomery.                                              */
+typedef struct {
+  const uint32_t* row_ptr; /* [num_constraints + 1] */
+  const uint32_t* col;     /* [nnz] wire index      */
+  const uint64_t* coeff;   /* [nnz][4]              */
+  uint64_t nnz;
+} g16_csr;
+
+/* ProvingKey<Bn254> as read_zkey builds it (src/zkey.rs:103-133), packed arrays on the host.     */
+typedef struct {
+  uint32_t n_vars;      /* N: wires incl. the constant 1 (HeaderGroth.n_vars)                    */
+  uint32_t n_public;    /* p (HeaderGroth.n_public); num_inputs = p + 1                          */
+  uint32_t domain_size; /* n = len(h_query)                                                      */
+  const uint8_t* a_query;    /* N x 64           (zkey section 5) */
+  const uint8_t* b_g1_query; /* N x 64           (section 6)      */
+  const uint8_t* b_g2_query; /* N x 128          (section 7)      */
+  const uint8_t* l_query;    /* (N-p-1) x 64     (section 8)      */
+  const uint8_t* h_query;    /* domain_size x 64 (section 9)      */
+  uint8_t alpha_g1[64], beta_g1[64], delta_g1[64];
+  uint8_t beta_g2[128], delta_g2[128];
+} g16_key_desc;
+
+typedef struct {
+  int device;      /* HIP device ordinal                                                        */
+  int rank, world; /* point-range shard of the MSMs owned by this ctx (world = 1: everything)   */
+  int window_bits; /* MSM window c; <= 0: automatic                                              */
+  int planes;      /* stored multiples 2^(c*D*j)P per point; <= 0: as many as fit (full = W)     */
+  int reserved[3];
+} g16_options;
+
+#define G16_PROOF_BYTES 256   /* A(64) | B(128) | C(64), affine */
+#define G16_PARTIAL_BYTES 384 /* A(64) | B1(64) | B2(128) | L(64) | H(64): one rank's MSM sums */
+
+enum { G16_QUERY_A = 0, G16_QUERY_B1 = 1, G16_QUERY_L = 2, G16_QUERY_H = 3 };
+
+/* Uploads the key and the matrices once, precomputes NTT tables and MSM point planes.
+ * Replaces: holding `(ProvingKey<Bn254>, ConstraintMatrices<Fr>)` from read_zkey (src/zkey.rs:53-60)
+ * across calls.  num_constraints = matrices.num_constraints (src/zkey.rs:171).                    */
+g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
+                          uint32_t num_constraints, const g16_options* opt, g16_ctx** out);
+void g16_ctx_destroy(g16_ctx* ctx);
+const char* g16_last_error(const g16_ctx* ctx); /* ctx may be NULL: error of the last failed create */
+
+/* CircomReduction::witness_map_from_matrices (src/circom/qap.rs:23-88).
+ * w: full_assignment, n_vars x 4 u64; h_out: domain_size x 4 u64 (natural order, Montgomery).   */
+g16_status g16_witness_map(g16_ctx* ctx, const uint64_t* w, size_t n_vars, uint64_t* h_out);
+
+/* VariableBaseMSM::msm_bigint over one resident query (ark-ec; reached from
+ * create_proof_with_assignment).  scalars: len x 4 u64 Montgomery Fr; pairs scalar i with
+ *   A/B1: query[1 + i]   (assignment = w[1..], as `msm(&query[1..], assignment)` upstream)
+ *   L   : l_query[i]     (aux assignment = w[num_inputs..])
+ *   H   : h_query[i]
+ * out: affine point (64 bytes).  Only valid on a world == 1 ctx.                                  */
+g16_status g16_msm_g1(g16_ctx* ctx, int which, const uint64_t* scalars, size_t len, uint8_t out[64]);
+/* Same for b_g2_query[1 + i]; out: 128 bytes.                                                     */
+g16_status g16_msm_g2(g16_ctx* ctx, const uint64_t* scalars, size_t len, uint8_t out[128]);
+
+/* Groth16::<Bn254,CircomReduction>::create_proof_with_reduction_and_matrices
+ * (benches/groth16.rs:52-60, src/zkey.rs:903-911) with pk/matrices/num_inputs/num_constraints
+ * taken from the ctx.  r, s: 4 u64 Montgomery Fr.  proof_out: A|B|C affine.  world == 1 only.     */
+g16_status g16_prove(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4], const uint64_t* w,
+                     size_t n_vars, uint8_t proof_out[G16_PROOF_BYTES]);
+/* Same with the witness already resident in HBM (device pointer, n_vars x 32 bytes).             */
+g16_status g16_prove_dev(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4], const void* w_dev,
+                         size_t n_vars, uint8_t proof_out[G16_PROOF_BYTES]);
+
+/* Multi-GPU (one process per GPU): every rank computes the sums of ITS point range, the host
+ * framework all-gathers the G16_PARTIAL_BYTES records (RCCL all_gather; EC addition is not an
+ * ncclRedOp, so "all-reduce" = all-gather + local add), then any rank finishes the proof.
+ * partials: world x G16_PARTIAL_BYTES in rank order.                                              */
+g16_status g16_prove_partial(g16_ctx* ctx, const uint64_t* w, size_t n_vars,
+                             uint8_t partial_out[G16_PARTIAL_BYTES]);
+g16_status g16_prove_partial_dev(g16_ctx* ctx, const void* w_dev, size_t n_vars,
+                                 uint8_t partial_out[G16_PARTIAL_BYTES]);
+g16_status g16_prove_finish(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4],
+                            const uint8_t* partials, int world, uint8_t proof_out[G16_PROOF_BYTES]);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
+#define G16_N_STAGES 8
+g16_status g16_set_profiling(g16_ctx* ctx, int enabled);
+/* HIP-event times accumulated since the last call; resets the accumulators.                       */
+g16_status g16_stage_times(g16_ctx* ctx, float ms[G16_N_STAGES], uint32_t launches[G16_N_STAGES]);
+const char* g16_stage_name(int stage);
+/* sizes chosen at create time: out[0]=c_w out[1]=W_w out[2]=planes_w out[3]=D_w, [4..7] same for H,
+ * out[8] = domain_size, out[9] = log2(domain_size)                                               */
+g16_status g16_ctx_info(const g16_ctx* ctx, uint32_t out[16]);
+/* device pointer of the ctx's witness staging buffer (n_vars x 32 bytes) for g16_prove_dev        */
+void* g16_witness_buffer(g16_ctx* ctx);
+
+/* ---- debug / parity entry points (tests) ----------------------------------------------------- */
+/* In-place size-2^log_n NTT of host data, natural order in and out (ark-poly fft_in_place /
+ * ifft_in_place semantics).  algo 0: DIF kernels + bit-reversal; algo 1: bit-reversal + DIT.      */
+g16_status g16_debug_ntt(int device, uint64_t* data, int log_n, int inverse, int algo);
+
+/* ---- loaders (host side, C++): see g16_loaders.h ---------------------------------------------- */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G16_AMD_H */

@@ -1,0 +1,59 @@
+"""pytest configuration.
+
+Markers
+  gpu : needs a real MI355X (run by the driver with `-m gpu` through gpurun); everything else must
+        pass on a CPU-only box.
+
+Fixtures
+  oracle  : the CPU checker (oracle/bn254_ref.py) -- test infrastructure only
+  emu     : tests/emu/libg16_emu.so = the kernel sources compiled against the SIMT emulator
+            (test infrastructure only; never loaded by the package)
+  gpulib  : the product library libg16_amd.so (skips if it is not built)
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (run via gpurun)")
+    config.addinivalue_line("markers", "slow: takes more than ~20 s on the CPU")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import bn254_ref
+    return bn254_ref
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """Kernel sources built against the CPU SIMT emulator (tests only)."""
+    so = os.path.join(ROOT, "tests", "emu", "libg16_emu.so")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "circom_compat_amd", "csrc"), "emu", "-j8"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.fail("emulation build failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
+    from circom_compat_amd import _binding
+    return _binding.Library(so)
+
+
+@pytest.fixture(scope="session")
+def gpulib():
+    from circom_compat_amd import _binding
+    try:
+        return _binding.load()
+    except ImportError as e:
+        pytest.skip(str(e))
