@@ -52,8 +52,11 @@ def emu():
 
 @pytest.fixture(scope="session")
 def gpulib():
+    """The product library.  On a GPU box a missing build is a hard failure (no silent fallback)."""
     from circom_compat_amd import _binding
-    try:
-        return _binding.load()
-    except ImportError as e:
-        pytest.skip(str(e))
+    return _binding.load()
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def lib(request):
+    return request.getfixturevalue("emu" if request.param == "emu" else "gpulib")

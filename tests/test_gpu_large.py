@@ -1,0 +1,123 @@
+"""GPU-only parity at sizes the emulator cannot reach: multi-pass NTTs, big MSMs with closed-form
+expectations, skewed (0/1-heavy) witnesses, size-independent properties."""
+import random
+
+import numpy as np
+import pytest
+
+import bn254_ref as o
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _ntt(lib, arr, k, inverse, algo):
+    a = arr.copy()
+    lib.check(lib.g16_debug_ntt(0, a.ctypes.data, k, 1 if inverse else 0, algo))
+    return a
+
+
+@pytest.mark.parametrize("k", [13, 16])
+def test_ntt_vs_oracle_large(gpulib, k):
+    rng = random.Random(k)
+    x = H.rand_fr(rng, 1 << k)
+    arr = H.fr_mont_arr(x)
+    assert H.fr_from_mont_arr(_ntt(gpulib, arr, k, False, 0)) == o.ntt(x)
+    assert H.fr_from_mont_arr(_ntt(gpulib, arr, k, True, 0)) == o.ntt(x, inverse=True)
+    assert H.fr_from_mont_arr(_ntt(gpulib, arr, k, False, 1)) == o.ntt(x)
+
+
+@pytest.mark.parametrize("k", [20, 22])
+def test_ntt_properties_full_size(gpulib, k):
+    """size-independent properties at BASELINE sizes: DIF and DIT kernels agree, inverse(forward) = id,
+    and X[0] = sum x (checked on the host with numpy big-int free arithmetic on a sparse input)."""
+    n = 1 << k
+    rng = np.random.default_rng(k)
+    arr = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    arr[:, 3] &= np.uint64((1 << 60) - 1)          # < modulus, arbitrary Montgomery residues
+    f0 = _ntt(gpulib, arr, k, False, 0)
+    f1 = _ntt(gpulib, arr, k, False, 1)
+    assert np.array_equal(f0, f1)
+    back = _ntt(gpulib, f0, k, True, 0)
+    assert np.array_equal(back, arr)
+    # delta at position j -> X[i] = omega^(i*j): check a few entries against the oracle
+    j = 12345 % n
+    d = np.zeros((n, 4), dtype=np.uint64)
+    d[j] = H.fr_mont_arr([1])[0]
+    X = _ntt(gpulib, d, k, False, 0)
+    w = o.root_of_unity(n)
+    for i in (0, 1, 2, n // 2 + 7, n - 1):
+        assert H.fr_from_mont_arr(X[i:i + 1])[0] == pow(w, i * j, o.R_MOD)
+
+
+def _cycled_key(rng, N, dom, K=64):
+    base1 = [o.G1.mul(o.G1_GEN, rng.randrange(1, o.R_MOD)) for _ in range(K)]
+    base2 = [o.G2.mul(o.G2_GEN, rng.randrange(1, o.R_MOD)) for _ in range(K)]
+    b1 = H.g1_arr(base1)
+    b2 = H.g2_arr(base2)
+    idx = np.arange(N) % K
+    import circom_compat_amd as cc
+    vk = cc.VerifyingKey(o.g1_to_bytes(base1[0]), o.g2_to_bytes(base2[0]), o.g2_to_bytes(base2[1]),
+                         o.g2_to_bytes(base2[2]), b1[:2].copy())
+    pk = cc.ProvingKey(N, 1, dom, vk, o.g1_to_bytes(base1[1]), o.g1_to_bytes(base1[2]),
+                       b1[idx].copy(), b1[(idx + 1) % K].copy(), b2[idx].copy(),
+                       b1[(np.arange(N - 2) + 5) % K].copy(), b1[(np.arange(dom) * 3) % K].copy())
+    return pk, base1, base2, K
+
+
+def _closed_form(C, base, K, scal, shift):
+    sums = [0] * K
+    for i, s in enumerate(scal):
+        sums[(i + shift) % K] = (sums[(i + shift) % K] + s) % o.R_MOD
+    return C.sum([C.mul(base[j], sums[j]) for j in range(K)])
+
+
+@pytest.mark.parametrize("logn,skew", [(14, False), (16, True), (18, False)])
+def test_msm_closed_form_large(gpulib, logn, skew):
+    """points cycle through K distinct bases, so sum s_i P_i has an O(n) scalar-side closed form"""
+    import circom_compat_amd as cc
+    rng = random.Random(logn)
+    n = (1 << logn) - 3
+    N = n + 1
+    dom = 1 << logn
+    pk, base1, base2, K = _cycled_key(rng, N, dom)
+    mats = H.matrices_from_rows([[(1, 1)]] * (dom - 2), [[(1, 0)]] * (dom - 2), 2, N, gpulib)
+    pr = cc.Prover(pk, mats, lib=gpulib)
+    if skew:   # circom-like witness: mostly bits and small values
+        scal = [rng.choice((0, 1, 1, 1, 2, 255, rng.randrange(o.R_MOD))) for _ in range(n)]
+    else:
+        scal = H.rand_fr(rng, n)
+    sm = H.fr_mont_arr(scal)
+    assert pr.msm_g1(0, sm) == o.g1_to_bytes(_closed_form(o.G1, base1, K, scal, 1))
+    assert pr.msm_g1(1, sm) == o.g1_to_bytes(_closed_form(o.G1, base1, K, scal, 2))
+    assert pr.msm_g2(sm) == o.g2_to_bytes(_closed_form(o.G2, base2, K, scal, 1))
+    hs = H.rand_fr(rng, dom)
+    want = [0] * K
+    for i, s in enumerate(hs):
+        want[(i * 3) % K] = (want[(i * 3) % K] + s) % o.R_MOD
+    assert pr.msm_g1(3, H.fr_mont_arr(hs)) == o.g1_to_bytes(o.G1.sum([o.G1.mul(base1[j], want[j]) for j in range(K)]))
+
+
+def test_witness_map_vs_oracle_2p14(gpulib):
+    """squaring chain with m = 2^14 - 2 (three NTT passes): h element-for-element vs the oracle"""
+    import circom_compat_amd as cc
+    cons, w, n_vars, _ = H.squaring_chain(14)
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, gpulib)
+    h = cc.CircomReduction.witness_map_from_matrices(mats, 2, len(cons), w, lib=gpulib)
+    want = o.witness_map_from_matrices(a_rows, b_rows, 2, len(cons), w)
+    assert H.fr_from_mont_arr(h) == want
+
+
+def test_determinism(gpulib, golden):
+    """same inputs twice -> identical bytes (atomics only permute bucket order; group sums are exact)"""
+    import os
+    import circom_compat_amd as cc
+    rng = random.Random(9)
+    N = 5000
+    pk, *_ = _cycled_key(rng, N, 8192)
+    mats = H.matrices_from_rows([[(1, 1)]] * 8190, [[(1, 0)]] * 8190, 2, N, gpulib)
+    pr = cc.Prover(pk, mats, lib=gpulib)
+    w = H.fr_mont_arr([1] + H.rand_fr(rng, N - 1))
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    assert pr.prove(r, s, w).raw == pr.prove(r, s, w).raw

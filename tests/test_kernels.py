@@ -1,0 +1,186 @@
+"""Parity of every kernel stage with the oracle: NTT passes, CircomReduction witness map, MSM
+(sort / accumulate / combine / reduce), proof assembly, sharded partial/finish.
+
+Each case runs twice through the SAME C ABI:
+  [emu]  kernel sources stepped through on the CPU SIMT emulator (tests/emu) -- catches indexing and
+         algorithm bugs without a GPU; not a parity claim;
+  [gpu]  the product library on a real MI355X (`-m gpu`) -- THE parity tests: bit-exact against the
+         oracle and the reference's golden fixtures."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+
+import bn254_ref as o
+import helpers as H
+
+
+def _ntt(lib, vals, inverse, algo):
+    arr = H.fr_mont_arr(vals)
+    k = len(vals).bit_length() - 1
+    st = lib.g16_debug_ntt(0, arr.ctypes.data, k, 1 if inverse else 0, algo)
+    lib.check(st)
+    return H.fr_from_mont_arr(arr)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 10, 11, 12])
+def test_ntt_vs_oracle(lib, k):
+    rng = random.Random(k)
+    x = H.rand_fr(rng, 1 << k)
+    assert _ntt(lib, x, False, 0) == o.ntt(x)
+    assert _ntt(lib, x, True, 0) == o.ntt(x, inverse=True)
+    assert _ntt(lib, x, False, 1) == o.ntt(x)
+
+
+def test_ntt_small_matches_naive_dft(lib):
+    rng = random.Random(3)
+    x = H.rand_fr(rng, 16)
+    assert _ntt(lib, x, False, 0) == o.dft_naive(x)
+
+
+def _prover(lib, pk, mats, **kw):
+    import circom_compat_amd as cc
+    return cc.Prover(pk, mats, lib=lib, **kw)
+
+
+def test_witness_map_test_zkey(lib, golden):
+    """reference fixture test.zkey, w = [1,33,3,11] -> SURVEY Appendix C.1 h vector"""
+    import circom_compat_amd as cc
+    pk, mats = cc.read_zkey(os.path.join(golden, "test.zkey"), lib=lib)
+    assert (mats.num_instance_variables, mats.num_constraints) == (2, 1)
+    pr = _prover(lib, pk, mats)
+    h = H.fr_from_mont_arr(pr.witness_map([1, 33, 3, 11]))
+    assert h == [190042957931705914545745448213290365653268903107554486158945885339918534040,
+                 1419419912336859849922499081568465451015963211367001816420814749527554252505,
+                 21698199913907568871316484237715844311305012280401884867766642092812430274913,
+                 9524701523582778197584879850388312504848302205747610345200903552183809682204]
+    # CircomReduction surface (stateless call, witness-map-only ctx)
+    h2 = cc.CircomReduction.witness_map_from_matrices(mats, 2, 1, [1, 33, 3, 11], lib=lib)
+    assert H.fr_from_mont_arr(h2) == h
+
+
+def test_prove_test_zkey(lib, golden):
+    """prove on the reference's own zkey; bit-exact vs oracle and accepted by the pairing check
+    (= reference tests src/zkey.rs:875-919 with the rng pinned)"""
+    import circom_compat_amd as cc
+    data = open(os.path.join(golden, "test.zkey"), "rb").read()
+    pk, mats = cc.read_zkey(data, lib=lib)
+    opk, omats = o.read_zkey(data)
+    w = [1, 33, 3, 11]
+    for r, s in [(0, 0),
+                 (3413513218498352040262653353725127729454431939539290118844322056224532443637,
+                  6077776500692565155461894309070795882353485867345896979329447163197530625403)]:
+        proof = cc.Groth16.create_proof_with_reduction_and_matrices(pk, r, s, mats, 2, 1, w, lib=lib)
+        want = o.create_proof_with_reduction_and_matrices(opk, r, s, omats, 2, 1, w)
+        assert proof.raw == o.proof_to_bytes(want)
+        assert o.verify_proof(opk, [33], H.proof_from_bytes(proof.raw))
+        assert not o.verify_proof(opk, [34], H.proof_from_bytes(proof.raw))
+
+
+def test_witness_map_circuit2(lib, golden):
+    """131 constraints with very uneven rows (65-term rows), n = 256; witness from the shipped .wtns"""
+    import circom_compat_amd as cc
+    r1 = cc.R1CS.from_file(os.path.join(golden, "circuit2.r1cs"), lib=lib)
+    w = cc.read_wtns(os.path.join(golden, "circuit2.wtns"), lib=lib)
+    wi = H.fr_from_mont_arr(w)
+    oc = o.read_r1cs(open(os.path.join(golden, "circuit2.r1cs"), "rb").read())
+    assert wi == o.read_wtns(open(os.path.join(golden, "circuit2.wtns"), "rb").read())
+    a_rows, b_rows = o.matrices_from_r1cs(oc["constraints"])
+    mats = r1.matrices()
+    h = cc.CircomReduction.witness_map_from_matrices(mats, r1.num_inputs, r1.num_constraints, w, lib=lib)
+    want = o.witness_map_from_matrices(a_rows, b_rows, oc["num_inputs"], oc["n_constraints"], wi)
+    assert H.fr_from_mont_arr(h) == want
+
+
+@pytest.mark.parametrize("n,c,planes", [(5, 3, 0), (40, 4, 1), (40, 4, 3), (300, 7, 0), (300, 6, 2)])
+def test_msm_vs_oracle(lib, n, c, planes):
+    """G1 and G2 MSM through the resident-query entry points, several window/plane layouts"""
+    import circom_compat_amd as cc
+    rng = random.Random(n * 31 + c)
+    N = n + 1
+    pts1 = H.rand_g1(rng, 6)
+    pts2 = H.rand_g2(rng, 4)
+    A = [pts1[rng.randrange(6)] if rng.random() > 0.1 else None for _ in range(N)]
+    for i in range(2, N, 7):           # distinct multiples so buckets see many different points
+        A[i] = o.G1.mul(pts1[i % 6], i + 3)
+    B2 = [o.G2.mul(pts2[i % 4], i + 1) if i % 9 else None for i in range(N)]
+    pk = dict(n_vars=N, n_public=1, domain_size=0, alpha_g1=pts1[0], beta_g1=pts1[1],
+              beta_g2=pts2[0], gamma_g2=pts2[1], delta_g1=pts1[2], delta_g2=pts2[2], ic=pts1[:2],
+              a_query=A, b_g1_query=list(reversed(A)), b_g2_query=B2, l_query=A[2:], h_query=None)
+    # a trivial circuit with the right shape: m = 1 row, domain from m + num_inputs
+    m = 1
+    dom = o.domain_size_for(m + 2)
+    pk["domain_size"] = dom
+    pk["h_query"] = [A[(3 * i + 1) % N] for i in range(dom)]
+    mats = H.matrices_from_rows([[(1, 1)]], [[(1, 0)]], 2, N, lib)
+    pr = cc.Prover(H.pk_from_oracle(pk), mats, lib=lib, window_bits=c, planes=planes)
+    scal = H.rand_fr(rng, n)
+    scal[0] = 0
+    scal[1] = 1
+    scal[2] = o.R_MOD - 1
+    if n > 20:
+        for i in range(5, 20):
+            scal[i] = 1               # hot bucket
+        scal[20] = (1 << (c - 1))     # digit exactly half -> stays positive
+        scal[21] = (1 << (c - 1)) + 1 # first negative digit with carry
+    assert pr.msm_g1(0, scal) == o.g1_to_bytes(o.G1.msm(A[1:], scal))
+    assert pr.msm_g1(1, scal) == o.g1_to_bytes(o.G1.msm(pk["b_g1_query"][1:], scal))
+    assert pr.msm_g2(scal) == o.g2_to_bytes(o.G2.msm(B2[1:], scal))
+    assert pr.msm_g1(2, scal[:n - 1]) == o.g1_to_bytes(o.G1.msm(pk["l_query"], scal[:n - 1]))
+    hs = H.rand_fr(rng, dom)
+    assert pr.msm_g1(3, hs) == o.g1_to_bytes(o.G1.msm(pk["h_query"], hs))
+
+
+def test_msm_hot_bucket_split(lib):
+    """more than MSM_CHUNK * MSM_SMALL_MULTI equal scalars: exercises task splitting and the
+    workgroup-per-bucket combine"""
+    import circom_compat_amd as cc
+    rng = random.Random(5)
+    n = 256 * 33 + 50
+    N = n + 1
+    base = H.rand_g1(rng, 3)
+    A = [base[i % 3] for i in range(N)]
+    g2 = H.rand_g2(rng, 1)
+    pk = dict(n_vars=N, n_public=1, domain_size=4, alpha_g1=base[0], beta_g1=base[1], beta_g2=g2[0],
+              gamma_g2=g2[0], delta_g1=base[2], delta_g2=g2[0], ic=base[:2], a_query=A, b_g1_query=A,
+              b_g2_query=[g2[0]] * N, l_query=A[2:], h_query=base + base[:1])
+    mats = H.matrices_from_rows([[(1, 1)]], [[(1, 0)]], 2, N, lib)
+    pr = cc.Prover(H.pk_from_oracle(pk), mats, lib=lib, window_bits=5, planes=0)
+    scal = [1] * n
+    for i in range(0, n, 97):
+        scal[i] = rng.randrange(o.R_MOD)
+    # closed form: sum of scalars per distinct base point
+    sums = [0, 0, 0]
+    for i, s in enumerate(scal):
+        sums[(i + 1) % 3] = (sums[(i + 1) % 3] + s) % o.R_MOD
+    want = o.G1.sum([o.G1.mul(base[j], sums[j]) for j in range(3)])
+    assert pr.msm_g1(0, scal) == o.g1_to_bytes(want)
+
+
+def test_prove_synthetic_circuit_vs_oracle(lib):
+    """squaring-chain circuit with a trapdoor key: proof bytes == oracle, proof verifies,
+    wrong public input is rejected; also the world = 2 partial/finish path gives the same bytes"""
+    import circom_compat_amd as cc
+    cons, w, n_vars, n_pub = H.squaring_chain(4)       # m = 14, n = 16
+    rng = random.Random(42)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    opk = o.trapdoor_setup(cons, n_vars, n_pub, *tox)
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    omats = dict(a=a_rows, b=b_rows)
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, lib)
+    pk = H.pk_from_oracle(opk)
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    want = o.create_proof_with_reduction_and_matrices(opk, r, s, omats, 2, len(cons), w)
+    assert o.verify_proof(opk, w[1:2], want)
+    pr = cc.Prover(pk, mats, lib=lib)
+    proof = pr.prove(r, s, w)
+    assert proof.raw == o.proof_to_bytes(want)
+    assert not o.verify_proof(opk, [(w[1] + 1) % o.R_MOD], H.proof_from_bytes(proof.raw))
+    # sharded: two ranks, all-gather emulated by concatenation
+    parts = b""
+    for rank in range(2):
+        p2 = cc.Prover(pk, mats, lib=lib, rank=rank, world=2)
+        parts += p2.prove_partial(w)
+    assert p2.prove_finish(r, s, parts).raw == proof.raw
