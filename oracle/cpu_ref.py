@@ -1,0 +1,110 @@
+"""oracle/cpu_ref.py -- TEST INFRASTRUCTURE ONLY: ctypes wrapper of oracle/libg16_cpu_oracle.so
+(the multithreaded C restatement of the reference's CPU proving path, oracle/groth16_cpu.c).
+Used by tests/ as the large-size checker and by bench.py's cpu_baseline leg; never by the product."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class _Csr(C.Structure):
+    _fields_ = [("row_ptr", C.c_void_p), ("col", C.c_void_p), ("coeff", C.c_void_p), ("nnz", C.c_uint64)]
+
+
+class _Key(C.Structure):
+    _fields_ = [("n_vars", C.c_uint32), ("n_public", C.c_uint32), ("domain_size", C.c_uint32),
+                ("a_query", C.c_void_p), ("b_g1_query", C.c_void_p), ("b_g2_query", C.c_void_p),
+                ("l_query", C.c_void_p), ("h_query", C.c_void_p),
+                ("alpha_g1", C.c_uint8 * 64), ("beta_g1", C.c_uint8 * 64), ("delta_g1", C.c_uint8 * 64),
+                ("beta_g2", C.c_uint8 * 128), ("delta_g2", C.c_uint8 * 128)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libg16_cpu_oracle.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.check_call(["make", "-C", _HERE])
+        _LIB = C.CDLL(path)
+        _LIB.g16cpu_max_threads.restype = C.c_int
+    return _LIB
+
+
+def set_threads(n):
+    lib().g16cpu_set_threads(int(n))
+
+
+def max_threads():
+    return lib().g16cpu_max_threads()
+
+
+def _csr(rp, col, coeff):
+    c = _Csr()
+    c.row_ptr, c.col, c.coeff, c.nnz = rp.ctypes.data, col.ctypes.data, coeff.ctypes.data, col.shape[0]
+    return c
+
+
+def witness_map(a, b, num_inputs, m, w):
+    """a, b: objects with row_ptr/col/coeff numpy arrays (Montgomery); w (N,4) uint64 Montgomery"""
+    need = m + num_inputs
+    n = 1
+    while n < need:
+        n <<= 1
+    h = np.empty((n, 4), dtype=np.uint64)
+    dom = C.c_uint32()
+    ca, cb = _csr(a.row_ptr, a.col, a.coeff), _csr(b.row_ptr, b.col, b.coeff)
+    st = lib().g16cpu_witness_map(C.byref(ca), C.byref(cb), C.c_uint32(num_inputs), C.c_uint32(m),
+                                  C.c_void_p(w.ctypes.data), C.c_void_p(h.ctypes.data), C.byref(dom))
+    if st == 2:
+        raise ValueError("PolynomialDegreeTooLarge")
+    assert st == 0 and dom.value == n
+    return h
+
+
+def msm_g1(bases, scalars_mont):
+    out = np.empty(64, dtype=np.uint8)
+    lib().g16cpu_msm_g1(C.c_void_p(bases.ctypes.data), C.c_void_p(scalars_mont.ctypes.data),
+                        C.c_size_t(scalars_mont.shape[0]), C.c_void_p(out.ctypes.data))
+    return out.tobytes()
+
+
+def msm_g2(bases, scalars_mont):
+    out = np.empty(128, dtype=np.uint8)
+    lib().g16cpu_msm_g2(C.c_void_p(bases.ctypes.data), C.c_void_p(scalars_mont.ctypes.data),
+                        C.c_size_t(scalars_mont.shape[0]), C.c_void_p(out.ctypes.data))
+    return out.tobytes()
+
+
+def prove(pk, mats, r_mont, s_mont, w, want_h=False):
+    """pk: circom_compat_amd.ProvingKey-like (packed numpy arrays); mats: ConstraintMatrices-like"""
+    k = _Key()
+    k.n_vars, k.n_public, k.domain_size = pk.n_vars, pk.n_public, pk.domain_size
+    for name in ("a_query", "b_g1_query", "b_g2_query", "l_query", "h_query"):
+        setattr(k, name, getattr(pk, name).ctypes.data)
+    C.memmove(k.alpha_g1, bytes(pk.vk.alpha_g1), 64)
+    C.memmove(k.beta_g1, bytes(pk.beta_g1), 64)
+    C.memmove(k.delta_g1, bytes(pk.delta_g1), 64)
+    C.memmove(k.beta_g2, bytes(pk.vk.beta_g2), 128)
+    C.memmove(k.delta_g2, bytes(pk.vk.delta_g2), 128)
+    ca = _csr(mats.a.row_ptr, mats.a.col, mats.a.coeff)
+    cb = _csr(mats.b.row_ptr, mats.b.col, mats.b.coeff)
+    out = np.empty(256, dtype=np.uint8)
+    h = np.empty((pk.domain_size, 4), dtype=np.uint64) if want_h else None
+    st = lib().g16cpu_prove(C.byref(k), C.byref(ca), C.byref(cb), C.c_uint32(mats.num_constraints),
+                            C.c_void_p(r_mont.ctypes.data), C.c_void_p(s_mont.ctypes.data),
+                            C.c_void_p(w.ctypes.data), C.c_void_p(out.ctypes.data),
+                            C.c_void_p(h.ctypes.data) if want_h else None)
+    if st == 2:
+        raise ValueError("PolynomialDegreeTooLarge")
+    assert st == 0, st
+    return (out.tobytes(), h) if want_h else out.tobytes()
+
+
+def fft(data, log_n, inverse=False):
+    a = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    lib().g16cpu_fft(C.c_void_p(a.ctypes.data), C.c_int(log_n), C.c_int(1 if inverse else 0))
+    return a
