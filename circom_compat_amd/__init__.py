@@ -35,7 +35,8 @@ from ._binding import G16Error, SerializationError, SynthesisError  # noqa: F401
 
 __all__ = ["read_zkey", "R1CSFile", "R1CS", "CircomCircuit", "CircomReduction", "Groth16",
            "Prover", "ProvingKey", "VerifyingKey", "ConstraintMatrices", "Proof", "G16Error",
-           "SynthesisError", "SerializationError", "fr_from_ints", "fr_to_ints", "read_wtns"]
+           "SynthesisError", "SerializationError", "fr_from_ints", "fr_to_ints", "read_wtns",
+           "trapdoor_setup", "Csr"]
 
 FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
@@ -418,6 +419,62 @@ class Prover:
         keys = ["c_w", "W_w", "planes_w", "D_w", "c_h", "W_h", "planes_h", "D_h", "domain_size",
                 "log_n", "shard_w", "shard_h"]
         return dict(zip(keys, list(out)))
+
+
+def _transpose_csr(m: Csr, n_cols: int, extra=None) -> Csr:
+    """CSR (rows = constraints) -> CSR of the transpose (rows = wires).  extra: optional
+    (rows, cols, coeff) triplets appended before transposing."""
+    counts = np.diff(m.row_ptr.astype(np.int64))
+    rows = np.repeat(np.arange(m.num_rows, dtype=np.int64), counts)
+    cols = m.col.astype(np.int64)
+    vals = m.coeff
+    if extra is not None:
+        rows = np.concatenate([rows, np.asarray(extra[0], dtype=np.int64)])
+        cols = np.concatenate([cols, np.asarray(extra[1], dtype=np.int64)])
+        vals = np.concatenate([vals, np.asarray(extra[2], dtype=np.uint64).reshape(-1, 4)])
+    order = np.argsort(cols, kind="stable")
+    rp = np.zeros(n_cols + 1, dtype=np.int64)
+    np.cumsum(np.bincount(cols, minlength=n_cols), out=rp[1:])
+    return Csr(rp.astype(np.uint32), rows[order].astype(np.uint32), vals[order])
+
+
+def trapdoor_setup(a: Csr, b: Csr, c: Csr, n_vars: int, n_public: int, toxic: Sequence[int],
+                   device=0, lib: Optional[B.Library] = None) -> ProvingKey:
+    """Known-toxic-waste circom/snarkjs-style setup on the GPU (g16_setup_create): the key
+    Groth16::generate_random_parameters_with_reduction::<CircomReduction> would produce for
+    (tau, alpha, beta, gamma, delta) = toxic.  Used to mint the synthetic BASELINE keys."""
+    lib = lib or B.load()
+    m = a.num_rows
+    ni = n_public + 1
+    one = fr_from_ints([1], lib)
+    at = _transpose_csr(a, n_vars, (np.arange(m, m + ni), np.arange(ni), np.tile(one, (ni, 1))))
+    bt = _transpose_csr(b, n_vars)
+    ct = _transpose_csr(c, n_vars)
+    tox = fr_from_ints(list(toxic), lib)
+    h = C.c_void_p()
+    cat, cbt, cct = at.to_c(), bt.to_c(), ct.to_c()
+    st = lib.g16_setup_create(device, C.byref(cat), C.byref(cbt), C.byref(cct), n_vars, n_public, m,
+                              _np_ptr(tox), C.byref(h))
+    if st != B.G16_OK:
+        raise (SynthesisError if st == B.G16_ERR_DOMAIN_TOO_LARGE else G16Error)(st, "g16_setup_create failed")
+    handle = _Handle(lib, h, lib.g16_setup_destroy)
+    kd = B.KeyDesc()
+    icp = C.c_void_p()
+    cnt = C.c_uint32()
+    gamma = (C.c_uint8 * 128)()
+    lib.check(lib.g16_setup_key(h, C.byref(kd), C.byref(icp), C.byref(cnt), gamma))
+
+    def view(ptr, count, width):
+        if count == 0:
+            return np.zeros((0, width), dtype=np.uint8)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * width,)).reshape(count, width)
+
+    vk = VerifyingKey(bytes(kd.alpha_g1), bytes(kd.beta_g2), bytes(gamma), bytes(kd.delta_g2),
+                      view(icp, cnt.value, 64).copy())
+    return ProvingKey(kd.n_vars, kd.n_public, kd.domain_size, vk, bytes(kd.beta_g1), bytes(kd.delta_g1),
+                      view(kd.a_query, n_vars, 64), view(kd.b_g1_query, n_vars, 64),
+                      view(kd.b_g2_query, n_vars, 128), view(kd.l_query, n_vars - n_public - 1, 64),
+                      view(kd.h_query, kd.domain_size, 64), keepalive=handle)
 
 
 class CircomReduction:

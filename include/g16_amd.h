@@ -138,6 +138,22 @@ void* g16_witness_buffer(g16_ctx* ctx);
  * ifft_in_place semantics).  algo 0: DIF kernels + bit-reversal; algo 1: bit-reversal + DIT.      */
 g16_status g16_debug_ntt(int device, uint64_t* data, int log_n, int inverse, int algo);
 
+/* ---- synthetic keys (not on the proving path) --------------------- */
+/* Trapdoor (known toxic waste) circom/snarkjs-style setup on the GPU: what
+ * Groth16::generate_random_parameters_with_reduction::<CircomReduction> computes (call shape:
+ * reference tests/groth16.rs:25; H basis: CircomReduction::h_query_scalars, src/circom/qap.rs:90-105).
+ * at/bt/ct: TRANSPOSED constraint matrices (row = wire, col = constraint, Montgomery coefficients),
+ * `at` including the n_public+1 rows snarkjs appends (row m+i holds coefficient 1 on signal i).
+ * toxic: tau, alpha, beta, gamma, delta as 5 x 4 u64 Montgomery Fr.                               */
+typedef struct g16_setup g16_setup;
+g16_status g16_setup_create(int device, const g16_csr* at, const g16_csr* bt, const g16_csr* ct,
+                            uint32_t n_vars, uint32_t n_public, uint32_t num_constraints,
+                            const uint64_t* toxic, g16_setup** out);
+/* host arrays owned by the handle; ic: (n_public+1) x 64 bytes = vk.gamma_abc_g1                  */
+g16_status g16_setup_key(g16_setup* s, g16_key_desc* key, const uint8_t** ic, uint32_t* ic_count,
+                         uint8_t gamma_g2[128]);
+void g16_setup_destroy(g16_setup* s);
+
 /* ---- loaders (host side, C++): see g16_loaders.h ---------------------------------------------- */
 
 #ifdef __cplusplus

@@ -184,3 +184,27 @@ def test_prove_synthetic_circuit_vs_oracle(lib):
         p2 = cc.Prover(pk, mats, lib=lib, rank=rank, world=2)
         parts += p2.prove_partial(w)
     assert p2.prove_finish(r, s, parts).raw == proof.raw
+
+
+def test_trapdoor_setup_vs_oracle(lib):
+    """GPU key generator (g16_setup_create) == oracle trapdoor setup, point for point; the key then
+    proves and the proof verifies.  Mirrors reference tests/groth16.rs:11-40 (setup -> prove ->
+    verify) with the rng pinned and CircomReduction as the QAP."""
+    import circom_compat_amd as cc
+    cons, w, n_vars, n_pub = H.squaring_chain(3)       # m = 6, n = 8
+    rng = random.Random(77)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    opk = o.trapdoor_setup(cons, n_vars, n_pub, *tox)
+    rows = lambda k: [[(c, wdx) for wdx, c in con[k]] for con in cons]
+    a, b, c = (cc.Csr.from_rows(rows(k), lib) for k in range(3))
+    pk = cc.trapdoor_setup(a, b, c, n_vars, n_pub, tox, lib=lib)
+    want = H.pk_from_oracle(opk)
+    for name in ("a_query", "b_g1_query", "b_g2_query", "l_query", "h_query"):
+        assert np.array_equal(getattr(pk, name), getattr(want, name)), name
+    assert np.array_equal(pk.vk.gamma_abc_g1, want.vk.gamma_abc_g1)
+    for name in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2"):
+        assert bytes(getattr(pk.vk, name)) == bytes(getattr(want.vk, name)), name
+    assert bytes(pk.beta_g1) == bytes(want.beta_g1) and bytes(pk.delta_g1) == bytes(want.delta_g1)
+    mats = cc.ConstraintMatrices(2, n_vars - 1, len(cons), a, b)
+    proof = cc.Prover(pk, mats, lib=lib).prove(123, 456, w)
+    assert o.verify_proof(opk, w[1:2], H.proof_from_bytes(proof.raw))
