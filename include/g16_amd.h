@@ -138,6 +138,11 @@ void* g16_witness_buffer(g16_ctx* ctx);
  * ifft_in_place semantics).  algo 0: DIF kernels + bit-reversal; algo 1: bit-reversal + DIT.      */
 g16_status g16_debug_ntt(int device, uint64_t* data, int log_n, int inverse, int algo);
 
+/* Integer-ALU ceilings (measurement only): kind 0 = Fq Montgomery multiplications, 1 = raw
+ * v_mad_u64_u32, 2 = G1 mixed additions.  Returns elapsed seconds and the number of operations.  */
+g16_status g16_debug_alu_bench(int device, int kind, uint32_t blocks, uint32_t iters,
+                               double* seconds, double* ops);
+
 /* ---- synthetic keys (not on the proving path) --------------------- */
 /* Trapdoor (known toxic waste) circom/snarkjs-style setup on the GPU: what
  * Groth16::generate_random_parameters_with_reduction::<CircomReduction> computes (call shape:

@@ -1,0 +1,20 @@
+"""integer-ALU ceilings on the GPU (v_mad_u64_u32, Fq mul, G1 madd) -> gpurun_out/alu_bench.json"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from circom_compat_amd import _binding
+
+lib = _binding.load()
+out = {}
+for kind, name, blocks, iters in ((1, "v_mad_u64_u32", 4096, 4096), (0, "fq_mul", 4096, 512), (2, "g1_madd", 8192, 64)):
+    sec, ops = C.c_double(), C.c_double()
+    st = lib.g16_debug_alu_bench(0, kind, blocks, iters, C.byref(sec), C.byref(ops))
+    assert st == 0, st
+    out[name] = {"seconds": sec.value, "ops": ops.value, "ops_per_s": ops.value / sec.value}
+    print(name, out[name], flush=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "alu_bench.json"), "w"), indent=1)
