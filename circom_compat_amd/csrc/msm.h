@@ -18,6 +18,7 @@
 //    a thread (few partials) or a whole workgroup (many partials) per bucket.
 #pragma once
 #include "common.h"
+#include "ec29.h"
 
 namespace g16 {
 
@@ -58,11 +59,16 @@ struct MsmSort {
   size_t device_bytes() const;
 };
 
+// accumulator type of the kernels: XYZZ over the lazy 9 x 29-bit limbs (field29.h / ec29.h)
+template <class F>
+using MsmAcc = XYZZ29<typename Lazy<F>::type>;
+
 template <class F>
 struct MsmPoints {
   MsmConfig cfg;
   uint32_t count = 0;
-  DevBuf<Affine<F>> pts;  // [Pn][count]
+  // [Pn][count], PACKED INTERNAL form (Lazy<F>): canonical x * 2^261 mod q in the 8 words of an Fq
+  DevBuf<Affine<F>> pts;
   // uploads `count` affine points (packed Montgomery x|y, all-zero = infinity) and fills the planes
   void init(const Affine<F>* host_points, uint32_t count, const MsmConfig& cfg, hipStream_t stream);
   // same, from points already in device memory (key generator)
@@ -72,15 +78,16 @@ struct MsmPoints {
 
 template <class F>
 struct MsmWork {
-  DevBuf<XYZZ<F>> partial;  // one per task
-  DevBuf<XYZZ<F>> contrib;  // one per reduction chunk
-  DevBuf<XYZZ<F>> bsum;     // intermediate tree level
-  DevBuf<XYZZ<F>> wsum;     // one per bucket set
+  DevBuf<MsmAcc<F>> partial;  // one per task
+  DevBuf<MsmAcc<F>> contrib;  // one per reduction chunk
+  DevBuf<MsmAcc<F>> bsum;     // intermediate tree level
+  DevBuf<MsmAcc<F>> wsum;     // one per bucket set
   // sized for the larger of several sorts that will share this workspace
   void init(uint32_t max_tasks, uint32_t n_contrib, int max_sets);
 };
 
-// out_dev[0] = sum_i scalar_i * P_{i - idx_min} over the entries of `s` with idx >= idx_min.
+// out_dev[0] = sum_i scalar_i * P_{i - idx_min} over the entries of `s` with idx >= idx_min,
+// in the storage form (Montgomery R = 2^256) finalize.hip consumes.
 template <class F>
 void msm_run(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min, MsmWork<F>& work,
              XYZZ<F>* out_dev, hipStream_t stream, StageTimer* tm = nullptr);

@@ -20,15 +20,20 @@ constexpr int ACC_THREADS = 128;
 constexpr int COMB_THREADS = 64;
 constexpr int SUM_THREADS = 128;
 
+// plane 0 arrives in the storage form (Montgomery-256, as uploaded from the key); every plane is
+// left in the packed internal form.  ctx-create only.
 template <class F>
 __global__ void __launch_bounds__(128) k_precompute_planes(Affine<F>* pts, uint32_t count, int Pn,
                                                            int shift_bits) {
+  using LF = typename Lazy<F>::type;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  XYZZ<F> q = XYZZ<F>::from_affine(pts[i]);
+  const Aff29<LF> p0 = affine_from_mont256<F>(pts[i]);
+  pts[i] = store_packed_affine<F>(p0);
+  XYZZ29<LF> q = XYZZ29<LF>::from_affine(p0);
   for (int j = 1; j < Pn; ++j) {
     for (int s = 0; s < shift_bits; ++s) q.dbl_in_place();
-    pts[(size_t)j * count + i] = q.to_affine();
+    pts[(size_t)j * count + i] = store_packed_affine<F>(q.to_affine());
   }
 }
 
@@ -38,7 +43,8 @@ __global__ void __launch_bounds__(ACC_THREADS)
                         const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset,
                         const uint32_t* __restrict__ count, const MsmTask* __restrict__ tasks,
                         const uint32_t* __restrict__ ntask_off, uint32_t nb,
-                        XYZZ<F>* __restrict__ partial) {
+                        MsmAcc<F>* __restrict__ partial) {
+  using LF = typename Lazy<F>::type;
   const uint32_t total = ntask_off[nb];
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
@@ -48,14 +54,14 @@ __global__ void __launch_bounds__(ACC_THREADS)
     uint32_t len = cnt - first;
     if (len > (uint32_t)MSM_CHUNK) len = MSM_CHUNK;
     const uint32_t* e = entries + offset[tk.g] + first;
-    XYZZ<F> acc = XYZZ<F>::infinity();
+    XYZZ29<LF> acc = XYZZ29<LF>::infinity();
     for (uint32_t j = 0; j < len; ++j) {
       const uint32_t en = e[j];
       const uint32_t idx = en & MSM_IDX_MASK;
       if (idx < idx_min) continue;
       const uint32_t plane = (en >> MSM_IDX_BITS) & 31u;
-      Affine<F> p = pts[(size_t)plane * npts + (idx - idx_min)];
-      if (en >> 31) p.y = p.y.neg();
+      Aff29<LF> p = load_packed_affine<F>(pts[(size_t)plane * npts + (idx - idx_min)]);
+      if (en >> 31) p.y = p.y.neg().carry();
       acc.madd(p);
     }
     partial[t] = acc;
@@ -66,13 +72,13 @@ __global__ void __launch_bounds__(ACC_THREADS)
 template <class F>
 __global__ void __launch_bounds__(COMB_THREADS)
     k_combine_small(const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
-                    const uint32_t* __restrict__ ntask_off, XYZZ<F>* partial) {
+                    const uint32_t* __restrict__ ntask_off, MsmAcc<F>* partial) {
   const uint32_t n = meta[0];
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const uint32_t g = list[i];
     const uint32_t first = ntask_off[g], nt = ntask_off[g + 1] - first;
-    XYZZ<F> acc = partial[first];
+    MsmAcc<F> acc = partial[first];
     for (uint32_t k = 1; k < nt; ++k) acc.add(partial[first + k]);
     partial[first] = acc;
   }
@@ -80,19 +86,19 @@ __global__ void __launch_bounds__(COMB_THREADS)
 
 // block-wide tree sum through LDS; result valid in thread 0
 template <class F, int T>
-__device__ __forceinline__ XYZZ<F> block_sum(XYZZ<F> v, XYZZ<F>* sh) {
+__device__ __forceinline__ MsmAcc<F> block_sum(MsmAcc<F> v, MsmAcc<F>* sh) {
   const int t = threadIdx.x;
   sh[t] = v;
   __syncthreads();
   for (int off = T / 2; off > 0; off >>= 1) {
     if (t < off) {
-      XYZZ<F> a = sh[t];
+      MsmAcc<F> a = sh[t];
       a.add(sh[t + off]);
       sh[t] = a;
     }
     __syncthreads();
   }
-  XYZZ<F> r = sh[0];
+  MsmAcc<F> r = sh[0];
   __syncthreads();
   return r;
 }
@@ -101,16 +107,16 @@ __device__ __forceinline__ XYZZ<F> block_sum(XYZZ<F> v, XYZZ<F>* sh) {
 template <class F>
 __global__ void __launch_bounds__(COMB_THREADS)
     k_combine_large(const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
-                    const uint32_t* __restrict__ ntask_off, XYZZ<F>* partial) {
+                    const uint32_t* __restrict__ ntask_off, MsmAcc<F>* partial) {
   G16_DYN_SMEM(smem_raw);
-  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem_raw);
+  MsmAcc<F>* sh = reinterpret_cast<MsmAcc<F>*>(smem_raw);
   const uint32_t n = meta[1];
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
     const uint32_t g = list[i];
     const uint32_t first = ntask_off[g], nt = ntask_off[g + 1] - first;
-    XYZZ<F> acc = XYZZ<F>::infinity();
+    MsmAcc<F> acc = MsmAcc<F>::infinity();
     for (uint32_t k = threadIdx.x; k < nt; k += COMB_THREADS) acc.add(partial[first + k]);
-    XYZZ<F> tot = block_sum<F, COMB_THREADS>(acc, sh);
+    MsmAcc<F> tot = block_sum<F, COMB_THREADS>(acc, sh);
     if (threadIdx.x == 0) partial[first] = tot;
     __syncthreads();
   }
@@ -119,15 +125,15 @@ __global__ void __launch_bounds__(COMB_THREADS)
 // contribution of buckets [lo, lo+L) of one set: sum (b+1) S_b = sum (b-lo+1) S_b + lo * sum S_b
 template <class F>
 __global__ void __launch_bounds__(64)
-    k_bucket_reduce(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ ntask_off,
-                    uint32_t B, uint32_t chunks_per_set, uint32_t nchunks, XYZZ<F>* contrib) {
+    k_bucket_reduce(const MsmAcc<F>* __restrict__ partial, const uint32_t* __restrict__ ntask_off,
+                    uint32_t B, uint32_t chunks_per_set, uint32_t nchunks, MsmAcc<F>* contrib) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nchunks) return;
   const uint32_t set = q / chunks_per_set;
   const uint32_t lo = (q % chunks_per_set) * (uint32_t)MSM_RED_CHUNK;
   uint32_t hi = lo + MSM_RED_CHUNK;
   if (hi > B) hi = B;
-  XYZZ<F> run = XYZZ<F>::infinity(), acc = XYZZ<F>::infinity();
+  MsmAcc<F> run = MsmAcc<F>::infinity(), acc = MsmAcc<F>::infinity();
   for (uint32_t b = hi; b-- > lo;) {
     const uint32_t g = set * B + b;
     const uint32_t first = ntask_off[g];
@@ -135,7 +141,7 @@ __global__ void __launch_bounds__(64)
     acc.add(run);
   }
   if (lo != 0 && !run.is_inf()) {
-    XYZZ<F> m = XYZZ<F>::infinity();
+    MsmAcc<F> m = MsmAcc<F>::infinity();
     for (int bit = 31 - __clz(lo); bit >= 0; --bit) {
       m.dbl_in_place();
       if ((lo >> bit) & 1) m.add(run);
@@ -148,28 +154,28 @@ __global__ void __launch_bounds__(64)
 // tree-sum: block (set, blk) of a (sets x nblk) grid sums its slice of the `per_set` inputs of the set
 template <class F>
 __global__ void __launch_bounds__(SUM_THREADS)
-    k_set_sum(const XYZZ<F>* __restrict__ in, uint32_t per_set, uint32_t nblk, XYZZ<F>* out) {
+    k_set_sum(const MsmAcc<F>* __restrict__ in, uint32_t per_set, uint32_t nblk, MsmAcc<F>* out) {
   G16_DYN_SMEM(smem_raw);
-  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem_raw);
+  MsmAcc<F>* sh = reinterpret_cast<MsmAcc<F>*>(smem_raw);
   const uint32_t set = blockIdx.x / nblk, blk = blockIdx.x % nblk;
-  const XYZZ<F>* c = in + (size_t)set * per_set;
-  XYZZ<F> acc = XYZZ<F>::infinity();
+  const MsmAcc<F>* c = in + (size_t)set * per_set;
+  MsmAcc<F> acc = MsmAcc<F>::infinity();
   for (uint32_t k = blk * SUM_THREADS + threadIdx.x; k < per_set; k += nblk * SUM_THREADS)
     acc.add(c[k]);
-  XYZZ<F> tot = block_sum<F, SUM_THREADS>(acc, sh);
+  MsmAcc<F> tot = block_sum<F, SUM_THREADS>(acc, sh);
   if (threadIdx.x == 0) out[blockIdx.x] = tot;
 }
 
 // total = sum_d 2^(c*d) wsum[d]   (D == 1: plain copy)
 template <class F>
-__global__ void k_horner(const XYZZ<F>* wsum, int D, int c, XYZZ<F>* out) {
+__global__ void k_horner(const MsmAcc<F>* wsum, int D, int c, XYZZ<F>* out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  XYZZ<F> t = wsum[D - 1];
+  MsmAcc<F> t = wsum[D - 1];
   for (int d = D - 2; d >= 0; --d) {
     for (int s = 0; s < c; ++s) t.dbl_in_place();
     t.add(wsum[d]);
   }
-  out[0] = t;
+  out[0] = xyzz_to_mont256<F>(t);  // back to the storage form for finalize.hip
 }
 
 }  // namespace
@@ -183,9 +189,9 @@ void MsmPoints<F>::init_from_device(const Affine<F>* dev_points, uint32_t n, con
   if (!n) return;
   G16_HIP(hipMemcpyAsync(pts.p, dev_points, (size_t)n * sizeof(Affine<F>), hipMemcpyDeviceToDevice,
                          stream));
-  if (cfg.Pn > 1)
-    G16_LAUNCH((k_precompute_planes<F>), ceil_div(n, 128), 128, 0, stream, pts.p, n, cfg.Pn,
-               cfg.c * cfg.D);
+  // always: plane 0 is converted from the storage form to the packed internal form
+  G16_LAUNCH((k_precompute_planes<F>), ceil_div(n, 128), 128, 0, stream, pts.p, n, cfg.Pn,
+             cfg.c * cfg.D);
 }
 
 template <class F>
@@ -197,9 +203,9 @@ void MsmPoints<F>::init(const Affine<F>* host_points, uint32_t n, const MsmConfi
   if (!n) return;
   G16_HIP(hipMemcpyAsync(pts.p, host_points, (size_t)n * sizeof(Affine<F>), hipMemcpyHostToDevice,
                          stream));
-  if (cfg.Pn > 1)
-    G16_LAUNCH((k_precompute_planes<F>), ceil_div(n, 128), 128, 0, stream, pts.p, n, cfg.Pn,
-               cfg.c * cfg.D);
+  // always: plane 0 is converted from the storage form to the packed internal form
+  G16_LAUNCH((k_precompute_planes<F>), ceil_div(n, 128), 128, 0, stream, pts.p, n, cfg.Pn,
+             cfg.c * cfg.D);
 }
 
 template <class F>
@@ -230,22 +236,22 @@ void msm_run(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<
   id = tm ? tm->begin(ST_MSM_REDUCE, stream) : -1;
   G16_LAUNCH((k_combine_small<F>), 1024, COMB_THREADS, 0, stream, (const uint32_t*)s.multi_s.p,
              (const uint32_t*)s.meta.p, (const uint32_t*)s.ntask_off.p, work.partial.p);
-  G16_LAUNCH((k_combine_large<F>), 1024, COMB_THREADS, COMB_THREADS * sizeof(XYZZ<F>), stream,
+  G16_LAUNCH((k_combine_large<F>), 1024, COMB_THREADS, COMB_THREADS * sizeof(MsmAcc<F>), stream,
              (const uint32_t*)s.multi_l.p, (const uint32_t*)s.meta.p,
              (const uint32_t*)s.ntask_off.p, work.partial.p);
   const uint32_t cps = ceil_div(cfg.B, MSM_RED_CHUNK);
   const uint32_t nchunks = cps * (uint32_t)cfg.D;
   G16_LAUNCH((k_bucket_reduce<F>), ceil_div(nchunks, 64), 64, 0, stream,
-             (const XYZZ<F>*)work.partial.p, (const uint32_t*)s.ntask_off.p, cfg.B, cps, nchunks,
+             (const MsmAcc<F>*)work.partial.p, (const uint32_t*)s.ntask_off.p, cfg.B, cps, nchunks,
              work.contrib.p);
   // two-level tree: cps contributions -> nblk block sums -> 1 per set
   uint32_t nblk = ceil_div(cps, SUM_THREADS * 2);
   if (nblk > 256) nblk = 256;
-  G16_LAUNCH((k_set_sum<F>), (uint32_t)cfg.D * nblk, SUM_THREADS, SUM_THREADS * sizeof(XYZZ<F>),
-             stream, (const XYZZ<F>*)work.contrib.p, cps, nblk, work.bsum.p);
-  G16_LAUNCH((k_set_sum<F>), (uint32_t)cfg.D, SUM_THREADS, SUM_THREADS * sizeof(XYZZ<F>), stream,
-             (const XYZZ<F>*)work.bsum.p, nblk, 1u, work.wsum.p);
-  G16_LAUNCH((k_horner<F>), 1, 64, 0, stream, (const XYZZ<F>*)work.wsum.p, cfg.D, cfg.c, out_dev);
+  G16_LAUNCH((k_set_sum<F>), (uint32_t)cfg.D * nblk, SUM_THREADS, SUM_THREADS * sizeof(MsmAcc<F>),
+             stream, (const MsmAcc<F>*)work.contrib.p, cps, nblk, work.bsum.p);
+  G16_LAUNCH((k_set_sum<F>), (uint32_t)cfg.D, SUM_THREADS, SUM_THREADS * sizeof(MsmAcc<F>), stream,
+             (const MsmAcc<F>*)work.bsum.p, nblk, 1u, work.wsum.p);
+  G16_LAUNCH((k_horner<F>), 1, 64, 0, stream, (const MsmAcc<F>*)work.wsum.p, cfg.D, cfg.c, out_dev);
   if (tm) tm->end(id, stream);
 }
 
