@@ -21,6 +21,8 @@ struct g16_ctx {
   uint32_t N = 0, p = 0, n = 0, m = 0, num_inputs = 0;
   bool has_key = false;  // false: witness-map-only context (a_query == NULL at create)
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;  // finalize stages that overlap the MSMs
+  hipEvent_t ev_start = nullptr, ev_ab = nullptr, ev_side = nullptr;
   std::string err;
 
   WitnessMap wm;
@@ -37,6 +39,8 @@ struct g16_ctx {
   DevBuf<Fr> w_dev, h_dev, rs_dev;
   DevBuf<KeyHeaderDev> key_dev;
   DevBuf<ProofSums> sums_dev;
+  DevBuf<FinTables> fin_tab;
+  DevBuf<FinScratch> fin_scr;
   DevBuf<uint8_t> out_dev;  // proof (256) | partial (384) | gathered partials
   DevBuf<G1Affine> aff1;
   DevBuf<G2Affine> aff2;
@@ -95,8 +99,11 @@ void collect_times(g16_ctx* c) {
   if (c->timer.enabled) c->timer.collect(c->st_ms, c->st_cnt);
 }
 
-// MSMs of one proof on this ctx's shard; results left in sums_dev
-void run_msms(g16_ctx* c, const Fr* w_dev) {
+// MSMs of one proof on this ctx's shard; results left in sums_dev.  `after_ab` (optional) is
+// called once the A and B1 sums are enqueued: the single-GPU prover forks the variable-base part
+// of the finalisation onto the side stream there.
+template <class Hook>
+void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
   hipStream_t s = c->stream;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   ProofSums* S = c->sums_dev.p;
@@ -110,6 +117,7 @@ void run_msms(g16_ctx* c, const Fr* w_dev) {
   if (tm) tm->end(id, s);
   msm_run<Fq>(c->sort_w, c->ptsA, 0, c->work1, &S->A, s, tm);
   msm_run<Fq>(c->sort_w, c->ptsB1, 0, c->work1, &S->B1, s, tm);
+  after_ab();
   msm_run<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, &S->L, s, tm);
   msm_run<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, &S->B2, s, tm);
 
@@ -117,6 +125,10 @@ void run_msms(g16_ctx* c, const Fr* w_dev) {
   c->sort_h.run(c->h_dev.p + c->h_lo, c->h_hi - c->h_lo, /*mont=*/true, s);
   if (tm) tm->end(id, s);
   msm_run<Fq>(c->sort_h, c->ptsH, 0, c->work1, &S->H, s, tm);
+}
+
+void run_msms(g16_ctx* c, const Fr* w_dev) {
+  run_msms(c, w_dev, [] {});
 }
 
 g16_status check_w(g16_ctx* c, size_t n_vars) {
@@ -158,6 +170,10 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
   c->world = o.world;
   g16_status st = guarded(c, [&]() -> g16_status {
     G16_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    G16_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    G16_HIP(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+    G16_HIP(hipEventCreateWithFlags(&c->ev_ab, hipEventDisableTiming));
+    G16_HIP(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
     hipStream_t s = c->stream;
     c->N = key->n_vars;
     c->p = key->n_public;
@@ -187,6 +203,8 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     c->rs_dev.alloc(2);
     c->key_dev.alloc(1);
     c->sums_dev.alloc(1);
+    c->fin_tab.alloc(1);
+    c->fin_scr.alloc(1);
     c->out_dev.alloc(G16_PROOF_BYTES + G16_PARTIAL_BYTES * (size_t)(c->world + 1));
     c->aff1.alloc(1);
     c->aff2.alloc(1);
@@ -230,6 +248,9 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     memcpy(&kh.delta2, key->delta_g2, 128);
     memcpy(&kh.b2_0, key->b_g2_query, 128);
     G16_HIP(hipMemcpyAsync(c->key_dev.p, &kh, sizeof kh, hipMemcpyHostToDevice, s));
+    G16_HIP(hipMemsetAsync(c->sums_dev.p, 0, sizeof(ProofSums), s));  // all sums = infinity
+    G16_HIP(hipMemsetAsync(c->fin_scr.p, 0, sizeof(FinScratch), s));
+    fin_build_tables(c->key_dev.p, c->fin_tab.p, s);
     G16_HIP(hipStreamSynchronize(s));
     return G16_OK;
   });
@@ -248,10 +269,17 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
 void g16_ctx_destroy(g16_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->side) {
+    (void)hipStreamSynchronize(c->side);
+    (void)hipStreamDestroy(c->side);
+  }
   if (c->stream) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
   }
+  if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+  if (c->ev_ab) (void)hipEventDestroy(c->ev_ab);
+  if (c->ev_side) (void)hipEventDestroy(c->ev_side);
   delete c;
 }
 
@@ -336,9 +364,20 @@ g16_status g16_prove_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], 
     memcpy(rs, r, 32);
     memcpy(rs + 4, s_, 32);
     G16_HIP(hipMemcpyAsync(c->rs_dev.p, rs, 64, hipMemcpyHostToDevice, s));
-    run_msms(c, (const Fr*)w_dev);
+    // fork: the (r, s)-only part of the finalisation runs beside the witness map / MSMs
+    G16_HIP(hipEventRecord(c->ev_start, s));
+    G16_HIP(hipStreamWaitEvent(c->side, c->ev_start, 0));
+    fin_fixed(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, c->side);
+    run_msms(c, (const Fr*)w_dev, [&] {
+      // A and B1 are enqueued: g_a, g1_b and the two variable-base products overlap L / B2 / H
+      G16_HIP(hipEventRecord(c->ev_ab, s));
+      G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
+      fin_var(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->fin_scr.p, c->out_dev.p, c->side);
+      G16_HIP(hipEventRecord(c->ev_side, c->side));
+    });
+    G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));  // join
     int id = c->timer.enabled ? c->timer.begin(ST_FINALIZE, s) : -1;
-    finalize_proof(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->out_dev.p, s);
+    fin_final(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, s);
     c->timer.end(id, s);
     G16_HIP(hipMemcpyAsync(proof_out, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
     G16_HIP(hipStreamSynchronize(s));
@@ -404,7 +443,9 @@ g16_status g16_prove_finish(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4
     G16_HIP(hipMemcpyAsync(gathered, partials, (size_t)world * G16_PARTIAL_BYTES,
                            hipMemcpyHostToDevice, s));
     partials_to_sums(gathered, world, c->sums_dev.p, s);
-    finalize_proof(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->out_dev.p, s);
+    fin_fixed(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, s);
+    fin_var(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->fin_scr.p, c->out_dev.p, s);
+    fin_final(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, s);
     G16_HIP(hipMemcpyAsync(proof_out, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
     G16_HIP(hipStreamSynchronize(s));
     return G16_OK;

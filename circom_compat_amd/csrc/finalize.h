@@ -1,26 +1,57 @@
 // finalize.h -- the O(1) tail of ark-groth16's create_proof_with_assignment (equations in
 // SURVEY.md section 3.1; reached from reference src/zkey.rs:903-911): r/s blinding, C assembly and the
 // three into_affine conversions.
+//
+//   g_a  = r*delta1 + a_query[0] + MSM_A + alpha1
+//   g1_b = s*delta1 + b_g1_query[0] + MSM_B1 + beta1
+//   g2_b = s*delta2 + b_g2_query[0] + MSM_B2 + beta2
+//   g_c  = s*g_a + r*g1_b - (r*s)*delta1 + MSM_L + MSM_H
+//
+// Split in three kernels so that nothing but two point additions and the affine conversions sit
+// on the critical path of a proof:
+//   fin_fixed  needs only (r, s): r*delta1, s*delta1, rs*delta1, s*delta2 from per-key tables of
+//              2^i * delta (one table entry per scalar bit, tree-summed by a workgroup).  Launched
+//              on the side stream when the proof starts.
+//   fin_var    needs MSM_A, MSM_B1: forms g_a, g1_b, writes A, and runs the two variable-base
+//              multiplications s*g_a, r*g1_b (4-bit windows, one wave each) on the side stream
+//              while the L / B2 / H MSMs run on the main stream.
+//   fin_final  needs everything: g_c and g2_b assembly + the two remaining affine conversions.
 #pragma once
 #include "common.h"
+#include "ec29.h"
 
 namespace g16 {
 
-struct KeyHeaderDev {  // device-resident copy of the O(1) key points
+struct KeyHeaderDev {  // device-resident copy of the O(1) key points (storage form, as uploaded)
   G1Affine alpha1, beta1, delta1;
   G1Affine a0, b1_0;  // a_query[0], b_g1_query[0]
   G2Affine beta2, delta2, b2_0;
 };
 
-struct ProofSums {  // MSM outputs (device)
-  G1XYZZ A, B1, L, H;
-  G2XYZZ B2;
+struct ProofSums {  // MSM outputs (device), lazy internal form
+  G1XYZZ29 A, B1, L, H;
+  G2XYZZ29 B2;
 };
 
-// proof_dev: 256 bytes A|B|C affine.  rs_dev: r, s (Montgomery Fr).
-void finalize_proof(const KeyHeaderDev* key, const ProofSums* sums, const Fr* rs_dev,
-                    uint8_t* proof_dev, hipStream_t stream);
-// ProofSums -> 384-byte affine record A|B1|B2|L|H (one rank's contribution)
+struct FinTables {  // per key: 2^i * delta1, 2^i * delta2, i < 256
+  G1XYZZ29 d1[256];
+  G2XYZZ29 d2[256];
+};
+
+struct FinScratch {  // per proof
+  G1XYZZ29 rd1, sd1, rsd1;  // r*delta1, s*delta1, rs*delta1
+  G2XYZZ29 sd2;             // s*delta2
+  G1XYZZ29 sga, rgb;        // s*g_a, r*g1_b
+};
+
+void fin_build_tables(const KeyHeaderDev* key, FinTables* tab, hipStream_t stream);
+void fin_fixed(const FinTables* tab, const Fr* rs_dev, FinScratch* scr, hipStream_t stream);
+void fin_var(const KeyHeaderDev* key, const ProofSums* sums, const Fr* rs_dev, FinScratch* scr,
+             uint8_t* proof_dev, hipStream_t stream);
+void fin_final(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr,
+               uint8_t* proof_dev, hipStream_t stream);
+
+// ProofSums -> 384-byte affine record A|B1|B2|L|H in the storage form (one rank's contribution)
 void sums_to_partial(const ProofSums* sums, uint8_t* partial_dev, hipStream_t stream);
 // world x 384-byte records -> ProofSums (local EC adds: the "all-reduce" tail)
 void partials_to_sums(const uint8_t* partials_dev, int world, ProofSums* sums, hipStream_t stream);

@@ -1,88 +1,186 @@
-// finalize.hip -- proof assembly (see finalize.h).  O(1) group operations per proof:
-//   g_a  = r*delta1 + a_query[0] + MSM_A + alpha1
-//   g1_b = s*delta1 + b_g1_query[0] + MSM_B1 + beta1
-//   g2_b = s*delta2 + b_g2_query[0] + MSM_B2 + beta2
-//   g_c  = s*g_a + r*g1_b - (r*s)*delta1 + MSM_L + MSM_H
-// The independent scalar multiplications run in different lanes (G1) / a different wave (G2) of
-// one small workgroup.
+// finalize.hip -- proof assembly (see finalize.h).  All arithmetic on the lazy limbs of
+// field29.h / ec29.h; results are converted to the storage form (affine, Montgomery R = 2^256,
+// the zkey point encoding of reference src/zkey.rs:340-360) only when written to the proof.
 #include "finalize.h"
 
 namespace g16 {
 
 namespace {
 
-__global__ void __launch_bounds__(128) k_finalize(const KeyHeaderDev* key, const ProofSums* sums,
-                                                  const Fr* rs, uint8_t* proof) {
-  __shared__ G1XYZZ sh[4];  // 0: r*delta1 -> s*g_a, 1: s*delta1 -> r*g1_b, 2: rs*delta1
+constexpr int FIN_T = 128;
+
+template <class A>
+__device__ __forceinline__ A tree_sum(A v, A* sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int off = FIN_T / 2; off > 0; off >>= 1) {
+    if (t < off) {
+      A a = sh[t];
+      a.add(sh[t + off]);
+      sh[t] = a;
+    }
+    __syncthreads();
+  }
+  return sh[0];
+}
+
+template <class F>
+__device__ __forceinline__ Affine<F> to_storage_affine(const XYZZ29<typename Lazy<F>::type>& a) {
+  const auto p = a.to_affine();
+  if (p.inf) return Affine<F>::infinity();
+  return Affine<F>{p.x.to_mont256(), p.y.to_mont256()};
+}
+
+// block 0: G1 table, block 1: G2 table; thread 0 doubles 255 times (ctx-create only)
+__global__ void k_fin_tables(const KeyHeaderDev* key, FinTables* tab) {
+  if (threadIdx.x != 0) return;
+  if (blockIdx.x == 0) {
+    G1XYZZ29 q = G1XYZZ29::from_affine(affine_from_mont256<Fq>(key->delta1));
+    for (int i = 0; i < 256; ++i) {
+      tab->d1[i] = q;
+      q.dbl_in_place();
+    }
+  } else {
+    G2XYZZ29 q = G2XYZZ29::from_affine(affine_from_mont256<Fq2>(key->delta2));
+    for (int i = 0; i < 256; ++i) {
+      tab->d2[i] = q;
+      q.dbl_in_place();
+    }
+  }
+}
+
+__device__ __forceinline__ bool bit_of(const U256& k, int i) { return (k.v[i >> 5] >> (i & 31)) & 1u; }
+
+// blocks 0..2: k * delta1 for k = r, s, rs; block 3: s * delta2.  Thread t owns bits t and t+128.
+__global__ void __launch_bounds__(FIN_T) k_fin_fixed(const FinTables* tab, const Fr* rs,
+                                                     FinScratch* scr) {
+  G16_DYN_SMEM(smem_raw);
   const int t = threadIdx.x;
   const Fr r = rs[0], s = rs[1];
-  if (t < 3) {
-    const U256 k = (t == 0 ? r : (t == 1 ? s : r * s)).to_canonical();
-    sh[t] = G1XYZZ::from_affine(key->delta1).mul(k);
-  } else if (t == 64) {
-    G2XYZZ b = G2XYZZ::from_affine(key->delta2).mul(s.to_canonical());
-    b.madd(key->b2_0);
-    b.add(sums->B2);
-    b.madd(key->beta2);
-    *reinterpret_cast<G2Affine*>(proof + 64) = b.to_affine();
+  const int b = blockIdx.x;
+  const U256 k = (b == 0 ? r : (b == 1 || b == 3 ? s : r * s)).to_canonical();
+  if (b < 3) {
+    G1XYZZ29* sh = reinterpret_cast<G1XYZZ29*>(smem_raw);
+    G1XYZZ29 v = G1XYZZ29::infinity();
+    if (bit_of(k, t)) v = tab->d1[t];
+    if (bit_of(k, t + FIN_T)) v.add(tab->d1[t + FIN_T]);
+    G1XYZZ29 tot = tree_sum(v, sh);
+    if (t == 0) (b == 0 ? scr->rd1 : (b == 1 ? scr->sd1 : scr->rsd1)) = tot;
+  } else {
+    G2XYZZ29* sh = reinterpret_cast<G2XYZZ29*>(smem_raw);
+    G2XYZZ29 v = G2XYZZ29::infinity();
+    if (bit_of(k, t)) v = tab->d2[t];
+    if (bit_of(k, t + FIN_T)) v.add(tab->d2[t + FIN_T]);
+    G2XYZZ29 tot = tree_sum(v, sh);
+    if (t == 0) scr->sd2 = tot;
   }
-  __syncthreads();
-  if (t < 2) {
-    G1XYZZ g = sh[t];
-    g.madd(t == 0 ? key->a0 : key->b1_0);
-    g.add(t == 0 ? sums->A : sums->B1);
-    g.madd(t == 0 ? key->alpha1 : key->beta1);
-    if (t == 0) *reinterpret_cast<G1Affine*>(proof) = g.to_affine();
-    sh[t] = g.mul((t == 0 ? s : r).to_canonical());
+}
+
+// k * P, 4-bit fixed windows, MSB first; table in LDS (one lane works, latency-bound by design:
+// this runs beside the big MSMs)
+__device__ G1XYZZ29 var_mul(const G1XYZZ29& P, const U256& k, G1XYZZ29* tbl) {
+  tbl[0] = G1XYZZ29::infinity();
+  tbl[1] = P;
+  for (int i = 2; i < 16; ++i) {
+    G1XYZZ29 q = tbl[i - 1];
+    q.add(P);
+    tbl[i] = q;
   }
-  __syncthreads();
-  if (t == 0) {
-    G1XYZZ c = sh[0];
-    c.add(sh[1]);
-    c.add(sh[2].neg());
+  G1XYZZ29 acc = G1XYZZ29::infinity();
+  for (int w = 63; w >= 0; --w) {
+    for (int d = 0; d < 4; ++d) acc.dbl_in_place();
+    const uint32_t nib = (k.v[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (nib) acc.add(tbl[nib]);
+  }
+  return acc;
+}
+
+// block 0: g_a, A, s*g_a      block 1: g1_b, r*g1_b
+__global__ void __launch_bounds__(64) k_fin_var(const KeyHeaderDev* key, const ProofSums* sums,
+                                                const Fr* rs, FinScratch* scr, uint8_t* proof) {
+  __shared__ G1XYZZ29 tbl[16];
+  if (threadIdx.x != 0) return;
+  const int b = blockIdx.x;
+  G1XYZZ29 g = b == 0 ? scr->rd1 : scr->sd1;
+  g.madd(affine_from_mont256<Fq>(b == 0 ? key->a0 : key->b1_0));
+  g.add(b == 0 ? sums->A : sums->B1);
+  g.madd(affine_from_mont256<Fq>(b == 0 ? key->alpha1 : key->beta1));
+  if (b == 0) *reinterpret_cast<G1Affine*>(proof) = to_storage_affine<Fq>(g);
+  const U256 k = (b == 0 ? rs[1] : rs[0]).to_canonical();
+  (b == 0 ? scr->sga : scr->rgb) = var_mul(g, k, tbl);
+}
+
+// block 0: g_c -> C      block 1: g2_b -> B
+__global__ void __launch_bounds__(64) k_fin_final(const KeyHeaderDev* key, const ProofSums* sums,
+                                                  const FinScratch* scr, uint8_t* proof) {
+  if (threadIdx.x != 0) return;
+  if (blockIdx.x == 0) {
+    G1XYZZ29 c = scr->sga;
+    c.add(scr->rgb);
+    c.add(scr->rsd1.neg());
     c.add(sums->L);
     c.add(sums->H);
-    *reinterpret_cast<G1Affine*>(proof + 192) = c.to_affine();
+    *reinterpret_cast<G1Affine*>(proof + 192) = to_storage_affine<Fq>(c);
+  } else {
+    G2XYZZ29 b = scr->sd2;
+    b.madd(affine_from_mont256<Fq2>(key->b2_0));
+    b.add(sums->B2);
+    b.madd(affine_from_mont256<Fq2>(key->beta2));
+    *reinterpret_cast<G2Affine*>(proof + 64) = to_storage_affine<Fq2>(b);
   }
 }
 
-__global__ void __launch_bounds__(128) k_sums_to_partial(const ProofSums* sums, uint8_t* out) {
-  const int t = threadIdx.x;
-  if (t == 0) *reinterpret_cast<G1Affine*>(out) = sums->A.to_affine();
-  if (t == 1) *reinterpret_cast<G1Affine*>(out + 64) = sums->B1.to_affine();
-  if (t == 2) *reinterpret_cast<G1Affine*>(out + 256) = sums->L.to_affine();
-  if (t == 3) *reinterpret_cast<G1Affine*>(out + 320) = sums->H.to_affine();
-  if (t == 64) *reinterpret_cast<G2Affine*>(out + 128) = sums->B2.to_affine();
+__global__ void __launch_bounds__(64) k_sums_to_partial(const ProofSums* sums, uint8_t* out) {
+  if (threadIdx.x != 0) return;
+  switch (blockIdx.x) {
+    case 0: *reinterpret_cast<G1Affine*>(out) = to_storage_affine<Fq>(sums->A); break;
+    case 1: *reinterpret_cast<G1Affine*>(out + 64) = to_storage_affine<Fq>(sums->B1); break;
+    case 2: *reinterpret_cast<G1Affine*>(out + 256) = to_storage_affine<Fq>(sums->L); break;
+    case 3: *reinterpret_cast<G1Affine*>(out + 320) = to_storage_affine<Fq>(sums->H); break;
+    default: *reinterpret_cast<G2Affine*>(out + 128) = to_storage_affine<Fq2>(sums->B2); break;
+  }
 }
 
-__global__ void __launch_bounds__(128) k_partials_to_sums(const uint8_t* parts, int world,
-                                                          ProofSums* sums) {
-  const int t = threadIdx.x;
-  if (t < 4) {
-    const int off = t == 0 ? 0 : (t == 1 ? 64 : (t == 2 ? 256 : 320));
-    G1XYZZ acc = G1XYZZ::infinity();
+__global__ void __launch_bounds__(64) k_partials_to_sums(const uint8_t* parts, int world,
+                                                         ProofSums* sums) {
+  if (threadIdx.x != 0) return;
+  const int b = blockIdx.x;
+  if (b < 4) {
+    const int off = b == 0 ? 0 : (b == 1 ? 64 : (b == 2 ? 256 : 320));
+    G1XYZZ29 acc = G1XYZZ29::infinity();
     for (int k = 0; k < world; ++k)
-      acc.madd(*reinterpret_cast<const G1Affine*>(parts + (size_t)k * 384 + off));
-    (t == 0 ? sums->A : (t == 1 ? sums->B1 : (t == 2 ? sums->L : sums->H))) = acc;
-  } else if (t == 64) {
-    G2XYZZ acc = G2XYZZ::infinity();
+      acc.madd(affine_from_mont256<Fq>(*reinterpret_cast<const G1Affine*>(parts + (size_t)k * 384 + off)));
+    (b == 0 ? sums->A : (b == 1 ? sums->B1 : (b == 2 ? sums->L : sums->H))) = acc;
+  } else {
+    G2XYZZ29 acc = G2XYZZ29::infinity();
     for (int k = 0; k < world; ++k)
-      acc.madd(*reinterpret_cast<const G2Affine*>(parts + (size_t)k * 384 + 128));
+      acc.madd(affine_from_mont256<Fq2>(*reinterpret_cast<const G2Affine*>(parts + (size_t)k * 384 + 128)));
     sums->B2 = acc;
   }
 }
 
 }  // namespace
 
-void finalize_proof(const KeyHeaderDev* key, const ProofSums* sums, const Fr* rs_dev,
-                    uint8_t* proof_dev, hipStream_t stream) {
-  G16_LAUNCH(k_finalize, 1, 128, 0, stream, key, sums, rs_dev, proof_dev);
+void fin_build_tables(const KeyHeaderDev* key, FinTables* tab, hipStream_t stream) {
+  G16_LAUNCH(k_fin_tables, 2, 64, 0, stream, key, tab);
+}
+void fin_fixed(const FinTables* tab, const Fr* rs_dev, FinScratch* scr, hipStream_t stream) {
+  G16_LAUNCH(k_fin_fixed, 4, FIN_T, FIN_T * sizeof(G2XYZZ29), stream, tab, rs_dev, scr);
+}
+void fin_var(const KeyHeaderDev* key, const ProofSums* sums, const Fr* rs_dev, FinScratch* scr,
+             uint8_t* proof_dev, hipStream_t stream) {
+  G16_LAUNCH(k_fin_var, 2, 64, 0, stream, key, sums, rs_dev, scr, proof_dev);
+}
+void fin_final(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr,
+               uint8_t* proof_dev, hipStream_t stream) {
+  G16_LAUNCH(k_fin_final, 2, 64, 0, stream, key, sums, scr, proof_dev);
 }
 void sums_to_partial(const ProofSums* sums, uint8_t* partial_dev, hipStream_t stream) {
-  G16_LAUNCH(k_sums_to_partial, 1, 128, 0, stream, sums, partial_dev);
+  G16_LAUNCH(k_sums_to_partial, 5, 64, 0, stream, sums, partial_dev);
 }
 void partials_to_sums(const uint8_t* partials_dev, int world, ProofSums* sums, hipStream_t stream) {
-  G16_LAUNCH(k_partials_to_sums, 1, 128, 0, stream, partials_dev, world, sums);
+  G16_LAUNCH(k_partials_to_sums, 5, 64, 0, stream, partials_dev, world, sums);
 }
 
 }  // namespace g16

@@ -86,11 +86,11 @@ struct MsmWork {
   void init(uint32_t max_tasks, uint32_t n_contrib, int max_sets);
 };
 
-// out_dev[0] = sum_i scalar_i * P_{i - idx_min} over the entries of `s` with idx >= idx_min,
-// in the storage form (Montgomery R = 2^256) finalize.hip consumes.
+// out_dev[0] = sum_i scalar_i * P_{i - idx_min} over the entries of `s` with idx >= idx_min
+// (lazy internal form; finalize.hip converts to the storage form when it writes the proof).
 template <class F>
 void msm_run(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min, MsmWork<F>& work,
-             XYZZ<F>* out_dev, hipStream_t stream, StageTimer* tm = nullptr);
+             MsmAcc<F>* out_dev, hipStream_t stream, StageTimer* tm = nullptr);
 
 // Fr Montgomery -> canonical (ark-ff into_bigint), n elements
 void fr_to_canonical(const Fr* in, U256* out, uint32_t n, hipStream_t stream);

@@ -168,14 +168,14 @@ __global__ void __launch_bounds__(SUM_THREADS)
 
 // total = sum_d 2^(c*d) wsum[d]   (D == 1: plain copy)
 template <class F>
-__global__ void k_horner(const MsmAcc<F>* wsum, int D, int c, XYZZ<F>* out) {
+__global__ void k_horner(const MsmAcc<F>* wsum, int D, int c, MsmAcc<F>* out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   MsmAcc<F> t = wsum[D - 1];
   for (int d = D - 2; d >= 0; --d) {
     for (int s = 0; s < c; ++s) t.dbl_in_place();
     t.add(wsum[d]);
   }
-  out[0] = xyzz_to_mont256<F>(t);  // back to the storage form for finalize.hip
+  out[0] = t;
 }
 
 }  // namespace
@@ -218,7 +218,7 @@ void MsmWork<F>::init(uint32_t max_tasks, uint32_t n_contrib, int max_sets) {
 
 template <class F>
 void msm_run(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<F>& work,
-             XYZZ<F>* out_dev, hipStream_t stream, StageTimer* tm) {
+             MsmAcc<F>* out_dev, hipStream_t stream, StageTimer* tm) {
   const MsmConfig& cfg = s.cfg;
   const uint32_t nb = cfg.nb();
   const int acc_stage = sizeof(F) == sizeof(Fq) ? ST_MSM_ACC_G1 : ST_MSM_ACC_G2;

@@ -3,6 +3,6 @@
 namespace g16 {
 template struct MsmPoints<Fq>;
 template struct MsmWork<Fq>;
-template void msm_run<Fq>(const MsmSort&, const MsmPoints<Fq>&, uint32_t, MsmWork<Fq>&, XYZZ<Fq>*,
+template void msm_run<Fq>(const MsmSort&, const MsmPoints<Fq>&, uint32_t, MsmWork<Fq>&, MsmAcc<Fq>*,
                           hipStream_t, StageTimer*);
 }  // namespace g16

@@ -4,5 +4,5 @@ namespace g16 {
 template struct MsmPoints<Fq2>;
 template struct MsmWork<Fq2>;
 template void msm_run<Fq2>(const MsmSort&, const MsmPoints<Fq2>&, uint32_t, MsmWork<Fq2>&,
-                           XYZZ<Fq2>*, hipStream_t, StageTimer*);
+                           MsmAcc<Fq2>*, hipStream_t, StageTimer*);
 }  // namespace g16
