@@ -3,6 +3,8 @@
 // runs in the HIP kernels of ntt.hip / witness_map.hip / msm_*.hip / finalize.hip.
 #include "../../include/g16_amd.h"
 
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "finalize.h"
@@ -20,9 +22,11 @@ struct g16_ctx {
   int device = 0, rank = 0, world = 1;
   uint32_t N = 0, p = 0, n = 0, m = 0, num_inputs = 0;
   bool has_key = false;  // false: witness-map-only context (a_query == NULL at create)
+  bool overlap = true;   // G16_NO_OVERLAP=1: everything on one stream (A/B measurements)
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;  // finalize stages that overlap the MSMs
-  hipEvent_t ev_start = nullptr, ev_ab = nullptr, ev_side = nullptr;
+  hipStream_t aux = nullptr;   // witness map + H-query sort, beside the witness-scalar MSMs
+  hipEvent_t ev_start = nullptr, ev_ab = nullptr, ev_side = nullptr, ev_w = nullptr, ev_h = nullptr;
   std::string err;
 
   WitnessMap wm;
@@ -104,13 +108,21 @@ void collect_times(g16_ctx* c) {
 // of the finalisation onto the side stream there.
 template <class Hook>
 void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
-  hipStream_t s = c->stream;
+  hipStream_t s = c->stream, x = c->overlap ? c->aux : c->stream;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   ProofSums* S = c->sums_dev.p;
-  // witness map first (H needs h); the witness-only sort does not depend on it
-  int id = tm ? tm->begin(ST_WITNESS_NTT, s) : -1;
-  c->wm.run(w_dev, c->h_dev.p, s);
-  if (tm) tm->end(id, s);
+  // aux stream: witness map (integer-ALU bound) then the H-query sort (atomics/HBM bound).
+  // main stream: witness-scalar sort, then the A, B1, L, B2 MSMs (ALU bound).  The two streams
+  // pair a memory-bound kernel with an ALU-bound one most of the time.
+  G16_HIP(hipEventRecord(c->ev_w, s));  // w is resident (upload enqueued on the main stream)
+  G16_HIP(hipStreamWaitEvent(x, c->ev_w, 0));
+  int id = tm ? tm->begin(ST_WITNESS_NTT, x) : -1;
+  c->wm.run(w_dev, c->h_dev.p, x);
+  if (tm) tm->end(id, x);
+  id = tm ? tm->begin(ST_MSM_SORT, x) : -1;
+  c->sort_h.run(c->h_dev.p + c->h_lo, c->h_hi - c->h_lo, /*mont=*/true, x);
+  if (tm) tm->end(id, x);
+  G16_HIP(hipEventRecord(c->ev_h, x));
 
   id = tm ? tm->begin(ST_MSM_SORT, s) : -1;
   c->sort_w.run(w_dev + 1 + c->w_lo, c->w_hi - c->w_lo, /*mont=*/true, s);
@@ -121,9 +133,7 @@ void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
   msm_run<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, &S->L, s, tm);
   msm_run<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, &S->B2, s, tm);
 
-  id = tm ? tm->begin(ST_MSM_SORT, s) : -1;
-  c->sort_h.run(c->h_dev.p + c->h_lo, c->h_hi - c->h_lo, /*mont=*/true, s);
-  if (tm) tm->end(id, s);
+  G16_HIP(hipStreamWaitEvent(s, c->ev_h, 0));
   msm_run<Fq>(c->sort_h, c->ptsH, 0, c->work1, &S->H, s, tm);
 }
 
@@ -171,6 +181,10 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
   g16_status st = guarded(c, [&]() -> g16_status {
     G16_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     G16_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    G16_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    if (const char* e = getenv("G16_NO_OVERLAP")) c->overlap = !(e[0] == '1');
+    G16_HIP(hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming));
+    G16_HIP(hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_ab, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
@@ -273,6 +287,12 @@ void g16_ctx_destroy(g16_ctx* c) {
     (void)hipStreamSynchronize(c->side);
     (void)hipStreamDestroy(c->side);
   }
+  if (c->aux) {
+    (void)hipStreamSynchronize(c->aux);
+    (void)hipStreamDestroy(c->aux);
+  }
+  if (c->ev_w) (void)hipEventDestroy(c->ev_w);
+  if (c->ev_h) (void)hipEventDestroy(c->ev_h);
   if (c->stream) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);

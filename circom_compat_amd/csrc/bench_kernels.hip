@@ -3,6 +3,7 @@
 // it is measured here; bench.py / scripts report MSM time against it next to the HBM roofline.
 #include "../../include/g16_amd.h"
 #include "common.h"
+#include "ec29.h"
 
 using namespace g16;
 
@@ -54,6 +55,31 @@ __global__ void __launch_bounds__(128) k_bench_madd(G1XYZZ* out, uint32_t iters)
   out[t] = acc;
 }
 
+// kind 3: the same on the lazy 9 x 29-bit limbs (what k_bucket_accumulate<Fq> executes)
+__global__ void __launch_bounds__(128) k_bench_madd29(G1XYZZ29* out, uint32_t iters) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  Aff29<Fq29> p{Fq29::from_mont256(Fq::from_u32(t + 1)), Fq29::from_mont256(Fq::from_u32(t + 2)), false};
+  G1XYZZ29 acc{Fq29::from_mont256(Fq::from_u32(t + 3)), Fq29::from_mont256(Fq::from_u32(t + 4)),
+               Fq29::from_mont256(Fq::from_u32(t + 5)), Fq29::from_mont256(Fq::from_u32(t + 6))};
+  for (uint32_t i = 0; i < iters; ++i) {
+    acc.madd(p);
+    p.x = (p.x + acc.zz).carry();
+  }
+  out[t] = acc;
+}
+// kind 4: G2 lazy mixed additions
+__global__ void __launch_bounds__(128) k_bench_madd29_g2(G2XYZZ29* out, uint32_t iters) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  auto f = [&](uint32_t a) { return Fq2x29{Fq29::from_mont256(Fq::from_u32(t + a)), Fq29::from_mont256(Fq::from_u32(t + a + 100))}; };
+  Aff29<Fq2x29> p{f(1), f(2), false};
+  G2XYZZ29 acc{f(3), f(4), f(5), f(6)};
+  for (uint32_t i = 0; i < iters; ++i) {
+    acc.madd(p);
+    p.x = (p.x + acc.zz).carry();
+  }
+  out[t] = acc;
+}
+
 }  // namespace
 
 extern "C" g16_status g16_debug_alu_bench(int device, int kind, uint32_t blocks, uint32_t iters,
@@ -66,14 +92,16 @@ extern "C" g16_status g16_debug_alu_bench(int device, int kind, uint32_t blocks,
     hipEvent_t a, b;
     G16_HIP(hipEventCreate(&a));
     G16_HIP(hipEventCreate(&b));
-    const uint32_t threads = kind == 2 ? 128 : 256;
+    const uint32_t threads = kind >= 2 ? 128 : 256;
     DevBuf<uint8_t> buf;
-    buf.alloc((size_t)blocks * threads * 128);
+    buf.alloc((size_t)blocks * threads * 320);
     for (int rep = 0; rep < 2; ++rep) {  // first repetition warms up
       G16_HIP(hipEventRecord(a, nullptr));
       if (kind == 0) G16_LAUNCH(k_bench_fqmul, blocks, threads, 0, nullptr, (Fq*)buf.p, iters);
       else if (kind == 1) G16_LAUNCH(k_bench_mad, blocks, threads, 0, nullptr, (uint64_t*)buf.p, iters);
-      else G16_LAUNCH(k_bench_madd, blocks, threads, 0, nullptr, (G1XYZZ*)buf.p, iters);
+      else if (kind == 2) G16_LAUNCH(k_bench_madd, blocks, threads, 0, nullptr, (G1XYZZ*)buf.p, iters);
+      else if (kind == 3) G16_LAUNCH(k_bench_madd29, blocks, threads, 0, nullptr, (G1XYZZ29*)buf.p, iters);
+      else G16_LAUNCH(k_bench_madd29_g2, blocks, threads, 0, nullptr, (G2XYZZ29*)buf.p, iters);
       G16_HIP(hipEventRecord(b, nullptr));
       G16_HIP(hipEventSynchronize(b));
     }

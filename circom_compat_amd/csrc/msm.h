@@ -13,7 +13,7 @@
 //    no 254-step doubling chain at the end;
 //  * one counting sort of (bucket, point) pairs per *scalar vector*; A, B1, B2 and L reuse the same
 //    sorted list because they share the witness as scalars;
-//  * bucket filling is split into tasks of <= MSM_CHUNK entries so that skewed witnesses (most
+//  * bucket filling is split into equal tasks of <= cfg.chunk entries so that skewed witnesses (most
 //    circom wires are 0/1) cannot serialise on one hot bucket; partial sums are then combined by
 //    a thread (few partials) or a whole workgroup (many partials) per bucket.
 #pragma once
@@ -22,7 +22,7 @@
 
 namespace g16 {
 
-constexpr int MSM_CHUNK = 256;      // max entries one thread accumulates
+constexpr int MSM_CHUNK_DEFAULT = 64;  // max entries one thread accumulates (G16_MSM_CHUNK overrides)
 constexpr int MSM_SMALL_MULTI = 32; // buckets with <= this many partials are combined by one thread
 constexpr int MSM_RED_CHUNK = 8;    // buckets per thread in the weighted bucket reduction
 constexpr uint32_t MSM_IDX_BITS = 26;
@@ -34,6 +34,7 @@ struct MsmConfig {
   int Pn = 1;      // stored multiples (planes) per point
   int D = 0;       // bucket sets = ceil(W / Pn)
   uint32_t B = 0;  // buckets per set = 2^(c-1)
+  uint32_t chunk = MSM_CHUNK_DEFAULT;  // a bucket of n entries is split into ceil(n / chunk) equal tasks
   uint32_t nb() const { return (uint32_t)D * B; }
 };
 

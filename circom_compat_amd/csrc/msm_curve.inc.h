@@ -3,7 +3,7 @@
 //
 // Stages (all launched on one stream, no host round trips):
 //   k_precompute_planes   (ctx_create only) plane j of point P = 2^(c*D*j) * P, affine
-//   k_bucket_accumulate   THE hot kernel: one task = <= MSM_CHUNK sorted entries of one bucket,
+//   k_bucket_accumulate   THE hot kernel: one task = <= cfg.chunk sorted entries of one bucket,
 //                         mixed XYZZ additions of gathered affine points
 //   k_combine_small/large buckets that were split into several tasks get their partials summed
 //   k_bucket_reduce       sum_b (b+1) * S_b over chunks of MSM_RED_CHUNK buckets (running sums)
@@ -49,19 +49,40 @@ __global__ void __launch_bounds__(ACC_THREADS)
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const MsmTask tk = tasks[t];
+    // the bucket's cnt entries are split EVENLY over its nt tasks (lengths differ by <= 1), so the
+    // lanes of a wave run near-equal trip counts
     const uint32_t cnt = count[tk.g];
-    const uint32_t first = tk.k * (uint32_t)MSM_CHUNK;
-    uint32_t len = cnt - first;
-    if (len > (uint32_t)MSM_CHUNK) len = MSM_CHUNK;
+    const uint32_t nt = ntask_off[tk.g + 1] - ntask_off[tk.g];
+    const uint32_t base = cnt / nt, rem = cnt - base * nt;
+    const uint32_t first = tk.k * base + (tk.k < rem ? tk.k : rem);
+    const uint32_t len = base + (tk.k < rem ? 1u : 0u);
     const uint32_t* e = entries + offset[tk.g] + first;
     XYZZ29<LF> acc = XYZZ29<LF>::infinity();
-    for (uint32_t j = 0; j < len; ++j) {
-      const uint32_t en = e[j];
+    // software pipeline: the gather of entry j+1 (a random 64/128-byte HBM read, ~2 us under load)
+    // is in flight while the ~1600 multiply-adds of entry j execute
+    auto fetch = [&](uint32_t en, Affine<F>& raw) {
       const uint32_t idx = en & MSM_IDX_MASK;
-      if (idx < idx_min) continue;
-      const uint32_t plane = (en >> MSM_IDX_BITS) & 31u;
-      Aff29<LF> p = load_packed_affine<F>(pts[(size_t)plane * npts + (idx - idx_min)]);
+      if (idx >= idx_min) {
+        const uint32_t plane = (en >> MSM_IDX_BITS) & 31u;
+        raw = pts[(size_t)plane * npts + (idx - idx_min)];
+      } else {
+        raw = Affine<F>::infinity();  // entry below this query's range (public inputs of L)
+      }
+    };
+    // entries are read two iterations ahead, points one iteration ahead: neither latency is exposed
+    uint32_t en_next = len ? e[0] : 0u;
+    uint32_t en_next2 = len > 1 ? e[1] : 0u;
+    Affine<F> raw_next = Affine<F>::infinity();
+    if (len) fetch(en_next, raw_next);
+    for (uint32_t j = 0; j < len; ++j) {
+      // consume what the previous iteration fetched, THEN issue the next fetches, THEN compute:
+      // all waits happen on loads that have had a whole madd to complete
+      const uint32_t en = en_next;
+      Aff29<LF> p = load_packed_affine<F>(raw_next);
       if (en >> 31) p.y = p.y.neg().carry();
+      en_next = en_next2;
+      if (j + 2 < len) en_next2 = e[j + 2];
+      if (j + 1 < len) fetch(en_next, raw_next);
       acc.madd(p);
     }
     partial[t] = acc;
@@ -71,17 +92,14 @@ __global__ void __launch_bounds__(ACC_THREADS)
 // buckets split into 2..MSM_SMALL_MULTI tasks: one thread sums the partials into the first slot
 template <class F>
 __global__ void __launch_bounds__(COMB_THREADS)
-    k_combine_small(const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
-                    const uint32_t* __restrict__ ntask_off, MsmAcc<F>* partial) {
-  const uint32_t n = meta[0];
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint32_t g = list[i];
-    const uint32_t first = ntask_off[g], nt = ntask_off[g + 1] - first;
-    MsmAcc<F> acc = partial[first];
-    for (uint32_t k = 1; k < nt; ++k) acc.add(partial[first + k]);
-    partial[first] = acc;
-  }
+    k_combine_small(uint32_t nb, const uint32_t* __restrict__ ntask_off, MsmAcc<F>* partial) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  const uint32_t first = ntask_off[g], nt = ntask_off[g + 1] - first;
+  if (nt < 2 || nt > (uint32_t)MSM_SMALL_MULTI) return;
+  MsmAcc<F> acc = partial[first];
+  for (uint32_t k = 1; k < nt; ++k) acc.add(partial[first + k]);
+  partial[first] = acc;
 }
 
 // block-wide tree sum through LDS; result valid in thread 0
@@ -234,8 +252,8 @@ void msm_run(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<
   if (tm) tm->end(id, stream);
 
   id = tm ? tm->begin(ST_MSM_REDUCE, stream) : -1;
-  G16_LAUNCH((k_combine_small<F>), 1024, COMB_THREADS, 0, stream, (const uint32_t*)s.multi_s.p,
-             (const uint32_t*)s.meta.p, (const uint32_t*)s.ntask_off.p, work.partial.p);
+  G16_LAUNCH((k_combine_small<F>), ceil_div(nb, COMB_THREADS), COMB_THREADS, 0, stream, nb,
+             (const uint32_t*)s.ntask_off.p, work.partial.p);
   G16_LAUNCH((k_combine_large<F>), 1024, COMB_THREADS, COMB_THREADS * sizeof(MsmAcc<F>), stream,
              (const uint32_t*)s.multi_l.p, (const uint32_t*)s.meta.p,
              (const uint32_t*)s.ntask_off.p, work.partial.p);

@@ -5,6 +5,8 @@
 // queries A, B1, B2, L share one sorted list, the H query has its own.
 #include "msm.h"
 
+#include <stdlib.h>
+
 namespace g16 {
 
 MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
@@ -25,6 +27,10 @@ MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
   cfg.D = (cfg.W + pn - 1) / pn;
   cfg.Pn = (cfg.W + cfg.D - 1) / cfg.D;
   cfg.B = 1u << (c - 1);
+  if (const char* e = getenv("G16_MSM_CHUNK")) {
+    const int v = atoi(e);
+    if (v >= 8 && v <= 4096) cfg.chunk = (uint32_t)v;
+  }
   return cfg;
 }
 
@@ -89,11 +95,11 @@ __global__ void __launch_bounds__(256) k_digit_scatter(const U256* canon, uint32
   });
 }
 
-// ---- exclusive scan of L u32 values (optionally of ceil(x / MSM_CHUNK)), 1024 values per block
+// ---- exclusive scan of L u32 values (mode = 0) or of ceil(x / mode) (mode = chunk), 1024 values per block
 constexpr int SCAN_T = 256, SCAN_V = 4, SCAN_TILE = SCAN_T * SCAN_V;
 
 __device__ __forceinline__ uint32_t scan_xform(uint32_t x, int mode) {
-  return mode ? (x + MSM_CHUNK - 1) / MSM_CHUNK : x;
+  return mode ? (x + (uint32_t)mode - 1) / (uint32_t)mode : x;
 }
 
 // block-wide exclusive scan of one value per thread; returns the exclusive prefix, total in *tot
@@ -178,11 +184,9 @@ __global__ void __launch_bounds__(256) k_task_fill(const uint32_t* ntask_off, ui
   const uint32_t first = ntask_off[g];
   const uint32_t nt = ntask_off[g + 1] - first;
   for (uint32_t k = 0; k < nt; ++k) tasks[first + k] = MsmTask{g, k};
-  if (nt > (uint32_t)MSM_SMALL_MULTI) {
-    multi_l[atomicAdd(&meta[1], 1u)] = g;
-  } else if (nt > 1) {
-    multi_s[atomicAdd(&meta[0], 1u)] = g;
-  }
+  // hot buckets are rare: list them (atomics).  Buckets with 2..MSM_SMALL_MULTI tasks are the
+  // common case with small chunks: k_combine_small visits every bucket instead of a list.
+  if (nt > (uint32_t)MSM_SMALL_MULTI) multi_l[atomicAdd(&meta[1], 1u)] = g;
 }
 
 }  // namespace
@@ -205,10 +209,10 @@ void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   ntask_off.alloc((size_t)nb + 1);
   entries.alloc(M ? M : 1);
   const uint64_t nonempty = M < nb ? M : nb;
-  max_tasks = (uint32_t)(M / MSM_CHUNK + nonempty + 1);
+  max_tasks = (uint32_t)(M / cfg.chunk + nonempty + 1);
   tasks.alloc(max_tasks);
-  multi_s.alloc((size_t)(M / (MSM_CHUNK + 1)) + 2);
-  multi_l.alloc((size_t)(M / ((uint64_t)MSM_CHUNK * MSM_SMALL_MULTI + 1)) + 2);
+  multi_s.alloc((size_t)(M / (cfg.chunk + 1)) + 2);
+  multi_l.alloc((size_t)(M / ((uint64_t)cfg.chunk * MSM_SMALL_MULTI + 1)) + 2);
   meta.alloc(4);
   scan_tmp.alloc(ceil_div((uint64_t)nb + 1, SCAN_TILE) + 1);
 }
@@ -238,7 +242,7 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
   if (n)
     G16_LAUNCH(k_digit_scatter, ceil_div(n, 256), 256, 0, s, cs, n, cfg.c, cfg.W, cfg.D, cfg.B,
                cursor.p, entries.p);
-  scan_exclusive(count.p, nb, 1, ntask_off.p, nullptr, scan_tmp.p, s);
+  scan_exclusive(count.p, nb, (int)cfg.chunk, ntask_off.p, nullptr, scan_tmp.p, s);
   G16_LAUNCH(k_task_fill, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)ntask_off.p, nb, tasks.p,
              multi_s.p, multi_l.p, meta.p);
 }

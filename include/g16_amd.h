@@ -139,7 +139,8 @@ void* g16_witness_buffer(g16_ctx* ctx);
 g16_status g16_debug_ntt(int device, uint64_t* data, int log_n, int inverse, int algo);
 
 /* Integer-ALU ceilings (measurement only): kind 0 = Fq Montgomery multiplications, 1 = raw
- * v_mad_u64_u32, 2 = G1 mixed additions.  Returns elapsed seconds and the number of operations.  */
+ * v_mad_u64_u32, 2 = G1 mixed additions (saturated limbs), 3 / 4 = G1 / G2 mixed additions on the lazy
+ * limbs the MSM kernels use.  Returns elapsed seconds and the number of operations.                */
 g16_status g16_debug_alu_bench(int device, int kind, uint32_t blocks, uint32_t iters,
                                double* seconds, double* ops);
 

@@ -10,7 +10,8 @@ from circom_compat_amd import _binding
 
 lib = _binding.load()
 out = {}
-for kind, name, blocks, iters in ((1, "v_mad_u64_u32", 4096, 4096), (0, "fq_mul", 4096, 512), (2, "g1_madd", 8192, 64)):
+for kind, name, blocks, iters in ((1, "v_mad_u64_u32", 4096, 4096), (0, "fq_mul", 4096, 512), (2, "g1_madd", 8192, 64),
+                                  (3, "g1_madd_lazy29", 8192, 64), (4, "g2_madd_lazy29", 8192, 32)):
     sec, ops = C.c_double(), C.c_double()
     st = lib.g16_debug_alu_bench(0, kind, blocks, iters, C.byref(sec), C.byref(ops))
     assert st == 0, st
