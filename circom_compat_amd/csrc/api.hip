@@ -181,7 +181,15 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
   g16_status st = guarded(c, [&]() -> g16_status {
     G16_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     G16_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    G16_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    {
+      // the aux stream carries the memory/atomic-bound work that should slip in beside the
+      // ALU-bound MSM kernels: give its workgroups dispatch priority
+      int lo = 0, hi = 0;
+      G16_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      const char* pe = getenv("G16_AUX_PRIORITY");
+      const int want = pe ? atoi(pe) : 1;
+      G16_HIP(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, want ? hi : lo));
+    }
     if (const char* e = getenv("G16_NO_OVERLAP")) c->overlap = !(e[0] == '1');
     G16_HIP(hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming));

@@ -41,6 +41,11 @@ struct MsmConfig {
 // c_override / planes_override <= 0 selects the defaults for `len` scalars.
 MsmConfig msm_make_config(size_t len, int c_override, int planes_override);
 
+struct alignas(8) MsmPair {  // level-1 sort record
+  uint32_t x;  // entry
+  uint32_t y;  // global bucket id
+};
+
 struct MsmTask {
   uint32_t g;  // global bucket id d*B + bucket
   uint32_t k;  // chunk number inside the bucket
@@ -50,8 +55,9 @@ struct MsmTask {
 struct MsmSort {
   MsmConfig cfg;
   uint32_t cap = 0, len = 0, max_tasks = 0;
-  DevBuf<U256> canon;
+  DevBuf<MsmPair> part;  // level-1 output: (entry, bucket) pairs ordered by partition
   DevBuf<uint32_t> count, offset, cursor, ntask_off, entries, multi_s, multi_l, meta, scan_tmp;
+  DevBuf<uint32_t> gcount1, part_off, cursor1;  // level-1 partition sizes / offsets / cursors
   DevBuf<MsmTask> tasks;
 
   void init(uint32_t capacity, const MsmConfig& cfg);

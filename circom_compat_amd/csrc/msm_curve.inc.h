@@ -10,6 +10,8 @@
 //   k_set_sum             tree-sum of the chunk contributions of one bucket set
 //   k_horner              only when D > 1: fold the D bucket sets with c doublings in between
 #pragma once
+#include <stdlib.h>
+
 #include "msm.h"
 
 namespace g16 {
@@ -242,7 +244,12 @@ void msm_run(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<
   const int acc_stage = sizeof(F) == sizeof(Fq) ? ST_MSM_ACC_G1 : ST_MSM_ACC_G2;
   // enough workgroups to fill 256 CUs several times over; tasks are grid-strided
   uint32_t grid = ceil_div(s.max_tasks, ACC_THREADS);
-  if (grid > 8192) grid = 8192;
+  static const uint32_t grid_cap = [] {
+    const char* e = getenv("G16_ACC_GRID");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? (uint32_t)v : 8192u;
+  }();
+  if (grid > grid_cap) grid = grid_cap;
   if (grid < 1) grid = 1;
   int id = tm ? tm->begin(acc_stage, stream) : -1;
   G16_LAUNCH((k_bucket_accumulate<F>), grid, ACC_THREADS, 0, stream,

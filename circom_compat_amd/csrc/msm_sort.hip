@@ -44,9 +44,9 @@ __global__ void __launch_bounds__(256) k_fr_to_canonical(const Fr* in, U256* out
 
 // Walks the signed c-bit digits of canonical scalar i; emit(g, entry) for every non-zero digit.
 template <class Emit>
-__device__ __forceinline__ void for_each_digit(const U256* canon, uint32_t i, int c, int W, int D,
+__device__ __forceinline__ void for_each_digit(const U256& scalar, uint32_t i, int c, int W, int D,
                                                uint32_t B, Emit emit) {
-  const uint32_t* sp = canon[i].v;
+  const uint32_t* sp = scalar.v;
   const uint32_t mask = (1u << c) - 1u;
   const uint32_t half = 1u << (c - 1);
   uint32_t carry = 0;
@@ -77,22 +77,151 @@ __device__ __forceinline__ void for_each_digit(const U256* canon, uint32_t i, in
   }
 }
 
-__global__ void __launch_bounds__(256) k_digit_hist(const U256* canon, uint32_t n, int c, int W,
-                                                    int D, uint32_t B, uint32_t* count) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  for_each_digit(canon, i, c, W, D, B, [&](uint32_t g, uint32_t) { atomicAdd(&count[g], 1u); });
+// ---- two-level counting sort of the (bucket, entry) pairs ---------------------------------------
+// A single-level sort needs one global atomic per entry and per pass (2 x 58.7 M at n = 2^22:
+// 8.7 ms).  Here every pass aggregates in LDS first:
+//   level 1: partition by the top bits of the bucket id (<= 1024 partitions); per tile of 2048
+//            scalars one LDS histogram, one global atomic per (tile, partition);
+//   level 2: inside a partition-ordered array a chunk of 16 K entries spans a contiguous range of
+//            <= 4096 buckets: LDS histogram / LDS ranks again, one global atomic per (chunk, bucket).
+// Order inside a bucket is arbitrary (EC addition commutes), which is what makes atomics-based
+// ranks admissible.  The outputs (count, offset, entries) are those of the single-level sort.
+constexpr int P1_THREADS = 256, P1_PER_THREAD = 8, P1_TILE = P1_THREADS * P1_PER_THREAD;
+constexpr int P1_MAX_BINS = 1024;
+constexpr int P2_THREADS = 256, P2_CHUNK = 16384, P2_BINS = 4096;
+
+struct SortGeom {
+  int c, W, D;
+  uint32_t B;
+  int sh;          // partition = bucket >> sh
+  uint32_t bins1;  // number of partitions
+};
+
+template <bool MONT>
+__device__ __forceinline__ U256 load_scalar(const void* scalars, uint32_t i) {
+  if (MONT) return reinterpret_cast<const Fr*>(scalars)[i].to_canonical();  // ark-ff into_bigint
+  return reinterpret_cast<const U256*>(scalars)[i];
 }
 
-__global__ void __launch_bounds__(256) k_digit_scatter(const U256* canon, uint32_t n, int c, int W,
-                                                       int D, uint32_t B, uint32_t* cursor,
-                                                       uint32_t* entries) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  for_each_digit(canon, i, c, W, D, B, [&](uint32_t g, uint32_t e) {
-    const uint32_t pos = atomicAdd(&cursor[g], 1u);
-    entries[pos] = e;
-  });
+template <bool MONT>
+__global__ void __launch_bounds__(P1_THREADS) k_part_count(const void* scalars, uint32_t n,
+                                                           SortGeom G, uint32_t* gcount1) {
+  __shared__ uint32_t h[P1_MAX_BINS];
+  const int tid = threadIdx.x;
+  for (uint32_t b = tid; b < G.bins1; b += P1_THREADS) h[b] = 0;
+  __syncthreads();
+  const uint32_t ntiles = (n + P1_TILE - 1) / P1_TILE;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int k = 0; k < P1_PER_THREAD; ++k) {
+      const uint32_t i = tile * P1_TILE + k * P1_THREADS + tid;
+      if (i >= n) continue;
+      const U256 sc = load_scalar<MONT>(scalars, i);
+      for_each_digit(sc, i, G.c, G.W, G.D, G.B, [&](uint32_t g, uint32_t) { atomicAdd(&h[g >> G.sh], 1u); });
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = tid; b < G.bins1; b += P1_THREADS)
+    if (h[b]) atomicAdd(&gcount1[b], h[b]);
+}
+
+template <bool MONT>
+__global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars, uint32_t n,
+                                                             SortGeom G, uint32_t* cursor1,
+                                                             MsmPair* part) {
+  __shared__ uint32_t h[P1_MAX_BINS];
+  const int tid = threadIdx.x;
+  const uint32_t ntiles = (n + P1_TILE - 1) / P1_TILE;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (uint32_t b = tid; b < G.bins1; b += P1_THREADS) h[b] = 0;
+    __syncthreads();
+    for (int k = 0; k < P1_PER_THREAD; ++k) {
+      const uint32_t i = tile * P1_TILE + k * P1_THREADS + tid;
+      if (i >= n) continue;
+      const U256 sc = load_scalar<MONT>(scalars, i);
+      for_each_digit(sc, i, G.c, G.W, G.D, G.B, [&](uint32_t g, uint32_t) { atomicAdd(&h[g >> G.sh], 1u); });
+    }
+    __syncthreads();
+    // reserve this tile's run in every partition; h[] becomes the running write cursor
+    for (uint32_t b = tid; b < G.bins1; b += P1_THREADS) {
+      const uint32_t cnt = h[b];
+      h[b] = cnt ? atomicAdd(&cursor1[b], cnt) : 0u;
+    }
+    __syncthreads();
+    for (int k = 0; k < P1_PER_THREAD; ++k) {
+      const uint32_t i = tile * P1_TILE + k * P1_THREADS + tid;
+      if (i >= n) continue;
+      const U256 sc = load_scalar<MONT>(scalars, i);
+      for_each_digit(sc, i, G.c, G.W, G.D, G.B, [&](uint32_t g, uint32_t e) {
+        const uint32_t pos = atomicAdd(&h[g >> G.sh], 1u);
+        part[pos] = MsmPair{e, g};
+      });
+    }
+    __syncthreads();
+  }
+}
+
+// level 2, pass A: per-bucket counts.  total = part_off[bins1] (device side).
+__global__ void __launch_bounds__(P2_THREADS) k_bucket_count(const MsmPair* part,
+                                                             const uint32_t* total_ptr, int sh,
+                                                             uint32_t* count) {
+  __shared__ uint32_t h[P2_BINS];
+  const int tid = threadIdx.x;
+  const uint32_t total = *total_ptr;
+  const uint32_t nchunks = (total + P2_CHUNK - 1) / P2_CHUNK;
+  for (uint32_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const uint32_t lo = ch * P2_CHUNK;
+    const uint32_t hi = lo + P2_CHUNK < total ? lo + P2_CHUNK : total;
+    const uint32_t gmin = (part[lo].y >> sh) << sh;
+    const uint32_t range = (((part[hi - 1].y >> sh) + 1u) << sh) - gmin;
+    if (range <= (uint32_t)P2_BINS) {
+      for (uint32_t b = tid; b < range; b += P2_THREADS) h[b] = 0;
+      __syncthreads();
+      for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) atomicAdd(&h[part[j].y - gmin], 1u);
+      __syncthreads();
+      for (uint32_t b = tid; b < range; b += P2_THREADS)
+        if (h[b]) atomicAdd(&count[gmin + b], h[b]);
+      __syncthreads();
+    } else {  // sparse buckets (tiny inputs or huge windows): plain global atomics
+      for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) atomicAdd(&count[part[j].y], 1u);
+    }
+  }
+}
+
+// level 2, pass B: final placement
+__global__ void __launch_bounds__(P2_THREADS) k_bucket_scatter(const MsmPair* part,
+                                                               const uint32_t* total_ptr, int sh,
+                                                               uint32_t* cursor, uint32_t* entries) {
+  __shared__ uint32_t h[P2_BINS];
+  const int tid = threadIdx.x;
+  const uint32_t total = *total_ptr;
+  const uint32_t nchunks = (total + P2_CHUNK - 1) / P2_CHUNK;
+  for (uint32_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const uint32_t lo = ch * P2_CHUNK;
+    const uint32_t hi = lo + P2_CHUNK < total ? lo + P2_CHUNK : total;
+    const uint32_t gmin = (part[lo].y >> sh) << sh;
+    const uint32_t range = (((part[hi - 1].y >> sh) + 1u) << sh) - gmin;
+    if (range <= (uint32_t)P2_BINS) {
+      for (uint32_t b = tid; b < range; b += P2_THREADS) h[b] = 0;
+      __syncthreads();
+      for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) atomicAdd(&h[part[j].y - gmin], 1u);
+      __syncthreads();
+      for (uint32_t b = tid; b < range; b += P2_THREADS) {
+        const uint32_t cnt = h[b];
+        h[b] = cnt ? atomicAdd(&cursor[gmin + b], cnt) : 0u;
+      }
+      __syncthreads();
+      for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) {
+        const MsmPair pe = part[j];
+        entries[atomicAdd(&h[pe.y - gmin], 1u)] = pe.x;
+      }
+      __syncthreads();
+    } else {
+      for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) {
+        const MsmPair pe = part[j];
+        entries[atomicAdd(&cursor[pe.y], 1u)] = pe.x;
+      }
+    }
+  }
 }
 
 // ---- exclusive scan of L u32 values (mode = 0) or of ceil(x / mode) (mode = chunk), 1024 values per block
@@ -202,7 +331,10 @@ void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   const uint32_t nb = cfg.nb();
   const uint64_t M = (uint64_t)cap * cfg.W;
   if (M >= ((uint64_t)1 << 32)) throw std::runtime_error("MSM entry count exceeds 2^32");
-  canon.alloc(cap ? cap : 1);
+  part.alloc(M ? M : 1);
+  gcount1.alloc(P1_MAX_BINS + 1);
+  part_off.alloc(P1_MAX_BINS + 1);
+  cursor1.alloc(P1_MAX_BINS + 1);
   count.alloc((size_t)nb + 1);
   offset.alloc((size_t)nb + 1);
   cursor.alloc((size_t)nb + 1);
@@ -218,7 +350,7 @@ void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
 }
 
 size_t MsmSort::device_bytes() const {
-  return canon.bytes() + count.bytes() + offset.bytes() + cursor.bytes() + ntask_off.bytes() +
+  return part.bytes() + count.bytes() + offset.bytes() + cursor.bytes() + ntask_off.bytes() +
          entries.bytes() + tasks.bytes() + multi_s.bytes() + multi_l.bytes();
 }
 
@@ -226,22 +358,41 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
   if (n > cap) throw std::runtime_error("MsmSort::run: more scalars than capacity");
   len = n;
   const uint32_t nb = cfg.nb();
-  const U256* cs;
-  if (mont) {
-    fr_to_canonical((const Fr*)scalars, canon.p, n, s);
-    cs = canon.p;
-  } else {
-    cs = (const U256*)scalars;
-  }
+  SortGeom G;
+  G.c = cfg.c;
+  G.W = cfg.W;
+  G.D = cfg.D;
+  G.B = cfg.B;
+  int bits = 0;
+  while (((uint64_t)1 << bits) < nb) ++bits;
+  G.sh = bits > 10 ? bits - 10 : 0;
+  G.bins1 = ((nb - 1) >> G.sh) + 1;
   G16_HIP(hipMemsetAsync(count.p, 0, ((size_t)nb + 1) * 4, s));
+  G16_HIP(hipMemsetAsync(gcount1.p, 0, (P1_MAX_BINS + 1) * 4, s));
   G16_HIP(hipMemsetAsync(meta.p, 0, 16, s));
-  if (n)
-    G16_LAUNCH(k_digit_hist, ceil_div(n, 256), 256, 0, s, cs, n, cfg.c, cfg.W, cfg.D, cfg.B,
-               count.p);
+  static const uint32_t grid_cap = [] {
+    const char* e = getenv("G16_SORT_GRID");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? (uint32_t)v : 2048u;
+  }();
+  uint32_t grid1 = ceil_div(n, P1_TILE);
+  if (grid1 > grid_cap) grid1 = grid_cap;
+  if (grid1 < 1) grid1 = 1;
+  uint32_t grid2 = ceil_div((uint64_t)n * cfg.W, P2_CHUNK);
+  if (grid2 > grid_cap) grid2 = grid_cap;
+  if (grid2 < 1) grid2 = 1;
+  // level 1: partition sizes, then partition
+  if (mont) G16_LAUNCH((k_part_count<true>), grid1, P1_THREADS, 0, s, scalars, n, G, gcount1.p);
+  else G16_LAUNCH((k_part_count<false>), grid1, P1_THREADS, 0, s, scalars, n, G, gcount1.p);
+  scan_exclusive(gcount1.p, G.bins1, 0, part_off.p, cursor1.p, scan_tmp.p, s);
+  if (mont) G16_LAUNCH((k_part_scatter<true>), grid1, P1_THREADS, 0, s, scalars, n, G, cursor1.p, part.p);
+  else G16_LAUNCH((k_part_scatter<false>), grid1, P1_THREADS, 0, s, scalars, n, G, cursor1.p, part.p);
+  // level 2: bucket sizes, offsets, final placement
+  const uint32_t* total = part_off.p + G.bins1;
+  G16_LAUNCH(k_bucket_count, grid2, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, count.p);
   scan_exclusive(count.p, nb, 0, offset.p, cursor.p, scan_tmp.p, s);
-  if (n)
-    G16_LAUNCH(k_digit_scatter, ceil_div(n, 256), 256, 0, s, cs, n, cfg.c, cfg.W, cfg.D, cfg.B,
-               cursor.p, entries.p);
+  G16_LAUNCH(k_bucket_scatter, grid2, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, cursor.p,
+             entries.p);
   scan_exclusive(count.p, nb, (int)cfg.chunk, ntask_off.p, nullptr, scan_tmp.p, s);
   G16_LAUNCH(k_task_fill, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)ntask_off.p, nb, tasks.p,
              multi_s.p, multi_l.p, meta.p);

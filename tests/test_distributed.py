@@ -54,7 +54,11 @@ WORKER = textwrap.dedent('''
 def test_two_rank_sharded_prove_gloo(emu, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + random.randrange(2000)))
+    import socket
+    with socket.socket() as sk:  # a port that is free right now (a fixed range collided with TIME_WAIT leftovers)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script), ROOT]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
