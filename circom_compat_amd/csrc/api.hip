@@ -253,11 +253,11 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     {
       const uint32_t nc_w = ceil_div(c->cfg_w.B, MSM_RED_CHUNK) * c->cfg_w.D;
       const uint32_t nc_h = ceil_div(c->cfg_h.B, MSM_RED_CHUNK) * c->cfg_h.D;
-      const uint32_t mt = c->sort_w.max_tasks > c->sort_h.max_tasks ? c->sort_w.max_tasks
-                                                                    : c->sort_h.max_tasks;
+      const uint32_t slots_w = c->cfg_w.nb() + c->cfg_w.lanes, slots_h = c->cfg_h.nb() + c->cfg_h.lanes;
+      const uint32_t mt = slots_w > slots_h ? slots_w : slots_h;
       const int dmax = c->cfg_w.D > c->cfg_h.D ? c->cfg_w.D : c->cfg_h.D;
       c->work1.init(mt, nc_w > nc_h ? nc_w : nc_h, dmax);
-      c->work2.init(c->sort_w.max_tasks, nc_w, c->cfg_w.D);
+      c->work2.init(slots_w, nc_w, c->cfg_w.D);
     }
 
     KeyHeaderDev kh;

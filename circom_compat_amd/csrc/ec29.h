@@ -66,6 +66,17 @@ struct XYZZ29 {
     x = X3;
     y = Y3;
   }
+  // rare tail of madd: x(P) == x(Q) exactly?  Kept out of line so that the hot loop's register
+  // allocation and instruction footprint do not pay for it.
+  static G16_NOINLINE XYZZ29 madd_rare(Aff29<LF> p, LF Pp, LF R, bool* handled) {
+    if (!Pp.is_zero_mod_p()) {
+      *handled = false;
+      return infinity();
+    }
+    *handled = true;
+    if (R.is_zero_mod_p()) return dbl_affine(p);
+    return infinity();
+  }
   // madd-2008-s: this += affine p.  8M + 2S, one merged reduction for Y3 in G1.
   G16_HD void madd(const Aff29<LF>& p) {
     if (p.inf) return;
@@ -80,13 +91,13 @@ struct XYZZ29 {
     LF S2 = p.y * zzz;  // M
     LF Pp = U2 - x;     // limbs within +-(2^29+8); |v| < 10p
     LF R = S2 - y;      // same; |v| < 10p
-    if (Pp.is_zero_mod_p()) {
-      if (R.is_zero_mod_p()) {
-        *this = dbl_affine(p);
-      } else {
-        *this = infinity();
+    if (Pp.maybe_zero_mod_p()) {  // ~2^-23 of the calls: exact test and the P = +-Q cases, out of line
+      bool handled;
+      XYZZ29 r = madd_rare(p, Pp, R, &handled);
+      if (handled) {
+        *this = r;
+        return;
       }
-      return;
     }
     LF PP = Pp.sqr();                              // M
     LF PPP = Pp * PP;                              // M

@@ -13,8 +13,10 @@
 #if defined(__HIPCC__) || defined(__HIP__)
 #include <hip/hip_runtime.h>
 #define G16_HD __host__ __device__ __forceinline__
+#define G16_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define G16_HD inline __attribute__((always_inline))
+#define G16_NOINLINE __attribute__((noinline))
 #endif
 
 namespace g16 {

@@ -338,10 +338,14 @@ struct F29 {
   // tiny; a random non-multiple passes that filter with probability ~2^-23 and then takes the
   // exact path.  Valid for |value| < 32 p.
   G16_HD bool is_zero_mod_p() const {
+    if (!maybe_zero_mod_p()) return false;
+    return canonical().limbs_all_zero();
+  }
+  // the cheap necessary condition alone (3 instructions); false positives ~2^-23
+  G16_HD bool maybe_zero_mod_p() const {
     const uint32_t j = ((uint32_t)l[0] * (0u - C::NINV)) & f29::MASK;  // v_0 / p_0 mod 2^29
     const uint32_t dist = j < (f29::MASK + 1u - j) ? j : (f29::MASK + 1u - j);
-    if (dist > 40u) return false;
-    return canonical().limbs_all_zero();
+    return dist <= 40u;
   }
 
   // ---- conversions -----------------------------------------------------------------------------
@@ -482,6 +486,7 @@ struct F29x2 {
     return (a * b - c * d).carry();
   }
   G16_HD bool is_zero_mod_p() const { return c0.is_zero_mod_p() && c1.is_zero_mod_p(); }
+  G16_HD bool maybe_zero_mod_p() const { return c0.maybe_zero_mod_p() && c1.maybe_zero_mod_p(); }
   G16_HD F29x2 canonical() const { return F29x2{c0.canonical(), c1.canonical()}; }
   static G16_HD F29x2 from_mont256(const Fq2& a) {
     return F29x2{B::from_mont256(a.c0), B::from_mont256(a.c1)};

@@ -13,17 +13,22 @@
 //    no 254-step doubling chain at the end;
 //  * one counting sort of (bucket, point) pairs per *scalar vector*; A, B1, B2 and L reuse the same
 //    sorted list because they share the witness as scalars;
-//  * bucket filling is split into equal tasks of <= cfg.chunk entries so that skewed witnesses (most
-//    circom wires are 0/1) cannot serialise on one hot bucket; partial sums are then combined by
-//    a thread (few partials) or a whole workgroup (many partials) per bucket.
+//  * bucket filling is balanced by ENTRIES, not by buckets: the sorted entry list is cut into
+//    cfg.lanes equal contiguous segments, one per lane of a persistent grid; a lane emits one partial
+//    sum per bucket it touches (slot = bucket + lane, unique and contiguous per bucket).  Every lane
+//    runs the same trip count whatever the bucket sizes, so skewed witnesses (most circom wires are
+//    0/1) neither serialise on a hot bucket nor leave lanes idle; a hot bucket simply spans many
+//    lanes and its partials are tree-summed by a workgroup.
 #pragma once
 #include "common.h"
 #include "ec29.h"
 
 namespace g16 {
 
-constexpr int MSM_CHUNK_DEFAULT = 64;  // max entries one thread accumulates (G16_MSM_CHUNK overrides)
-constexpr int MSM_SMALL_MULTI = 32; // buckets with <= this many partials are combined by one thread
+constexpr int MSM_ACC_THREADS = 128;    // workgroup of the accumulation kernel
+constexpr int MSM_ACC_BLOCKS = 2048;    // persistent grid: 4 waves per SIMD on 256 CUs (G16_ACC_GRID overrides)
+constexpr int MSM_MIN_SEG = 8;          // shortest per-lane segment
+constexpr int MSM_SMALL_MULTI = 32;     // buckets with <= this many partials are summed inside the reduce
 constexpr int MSM_RED_CHUNK = 8;    // buckets per thread in the weighted bucket reduction
 constexpr uint32_t MSM_IDX_BITS = 26;
 constexpr uint32_t MSM_IDX_MASK = (1u << MSM_IDX_BITS) - 1u;
@@ -34,7 +39,7 @@ struct MsmConfig {
   int Pn = 1;      // stored multiples (planes) per point
   int D = 0;       // bucket sets = ceil(W / Pn)
   uint32_t B = 0;  // buckets per set = 2^(c-1)
-  uint32_t chunk = MSM_CHUNK_DEFAULT;  // a bucket of n entries is split into ceil(n / chunk) equal tasks
+  uint32_t lanes = MSM_ACC_BLOCKS * MSM_ACC_THREADS;  // segments the entry list is cut into
   uint32_t nb() const { return (uint32_t)D * B; }
 };
 
@@ -46,19 +51,19 @@ struct alignas(8) MsmPair {  // level-1 sort record
   uint32_t y;  // global bucket id
 };
 
-struct MsmTask {
-  uint32_t g;  // global bucket id d*B + bucket
-  uint32_t k;  // chunk number inside the bucket
-};
+// entries per lane for a list of M entries cut over `lanes` lanes (same formula on host and device)
+G16_HD uint32_t msm_seg_len(uint32_t M, uint32_t lanes) {
+  uint32_t S = (uint32_t)(((uint64_t)M + lanes - 1) / lanes);
+  return S < (uint32_t)MSM_MIN_SEG ? (uint32_t)MSM_MIN_SEG : S;
+}
 
 // Sorted (bucket -> entries) view of one scalar vector.  entry = idx | plane << 26 | neg << 31.
 struct MsmSort {
   MsmConfig cfg;
-  uint32_t cap = 0, len = 0, max_tasks = 0;
+  uint32_t cap = 0, len = 0;
   DevBuf<MsmPair> part;  // level-1 output: (entry, bucket) pairs ordered by partition
-  DevBuf<uint32_t> count, offset, cursor, ntask_off, entries, multi_s, multi_l, meta, scan_tmp;
+  DevBuf<uint32_t> count, offset, cursor, entries, multi_l, meta, scan_tmp;  // meta[1] = #hot buckets
   DevBuf<uint32_t> gcount1, part_off, cursor1;  // level-1 partition sizes / offsets / cursors
-  DevBuf<MsmTask> tasks;
 
   void init(uint32_t capacity, const MsmConfig& cfg);
   // scalars: `n` field elements (Montgomery Fr when mont, else canonical U256) in device memory
@@ -85,12 +90,12 @@ struct MsmPoints {
 
 template <class F>
 struct MsmWork {
-  DevBuf<MsmAcc<F>> partial;  // one per task
+  DevBuf<MsmAcc<F>> partial;  // slot = bucket + lane: nb + lanes slots
   DevBuf<MsmAcc<F>> contrib;  // one per reduction chunk
   DevBuf<MsmAcc<F>> bsum;     // intermediate tree level
   DevBuf<MsmAcc<F>> wsum;     // one per bucket set
   // sized for the larger of several sorts that will share this workspace
-  void init(uint32_t max_tasks, uint32_t n_contrib, int max_sets);
+  void init(uint32_t n_slots, uint32_t n_contrib, int max_sets);
 };
 
 // out_dev[0] = sum_i scalar_i * P_{i - idx_min} over the entries of `s` with idx >= idx_min

@@ -3,10 +3,11 @@
 //
 // Stages (all launched on one stream, no host round trips):
 //   k_precompute_planes   (ctx_create only) plane j of point P = 2^(c*D*j) * P, affine
-//   k_bucket_accumulate   THE hot kernel: one task = <= cfg.chunk sorted entries of one bucket,
-//                         mixed XYZZ additions of gathered affine points
-//   k_combine_small/large buckets that were split into several tasks get their partials summed
-//   k_bucket_reduce       sum_b (b+1) * S_b over chunks of MSM_RED_CHUNK buckets (running sums)
+//   k_bucket_accumulate   THE hot kernel: one lane = one equal segment of the sorted entry list,
+//                         mixed XYZZ additions of gathered affine points, one partial per bucket touched
+//   k_combine_large       hot buckets (> MSM_SMALL_MULTI partials) get their partials tree-summed
+//   k_bucket_reduce       sum_b (b+1) * S_b over chunks of MSM_RED_CHUNK buckets (running sums);
+//                         S_b = sum of the bucket's <= MSM_SMALL_MULTI partials
 //   k_set_sum             tree-sum of the chunk contributions of one bucket set
 //   k_horner              only when D > 1: fold the D bucket sets with c doublings in between
 #pragma once
@@ -18,7 +19,7 @@ namespace g16 {
 
 namespace {
 
-constexpr int ACC_THREADS = 128;
+constexpr int ACC_THREADS = MSM_ACC_THREADS;
 constexpr int COMB_THREADS = 64;
 constexpr int SUM_THREADS = 128;
 
@@ -39,29 +40,36 @@ __global__ void __launch_bounds__(128) k_precompute_planes(Affine<F>* pts, uint3
   }
 }
 
+// index of the bucket that holds sorted position `pos`: the g with offset[g] <= pos < offset[g+1]
+__device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offset, uint32_t nb,
+                                              uint32_t pos) {
+  uint32_t lo = 0, hi = nb;  // invariant: offset[lo] <= pos < offset[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (offset[mid] <= pos) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
 template <class F>
 __global__ void __launch_bounds__(ACC_THREADS)
     k_bucket_accumulate(const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min,
                         const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset,
-                        const uint32_t* __restrict__ count, const MsmTask* __restrict__ tasks,
-                        const uint32_t* __restrict__ ntask_off, uint32_t nb,
-                        MsmAcc<F>* __restrict__ partial) {
+                        uint32_t nb, uint32_t lanes, MsmAcc<F>* __restrict__ partial) {
   using LF = typename Lazy<F>::type;
-  const uint32_t total = ntask_off[nb];
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const MsmTask tk = tasks[t];
-    // the bucket's cnt entries are split EVENLY over its nt tasks (lengths differ by <= 1), so the
-    // lanes of a wave run near-equal trip counts
-    const uint32_t cnt = count[tk.g];
-    const uint32_t nt = ntask_off[tk.g + 1] - ntask_off[tk.g];
-    const uint32_t base = cnt / nt, rem = cnt - base * nt;
-    const uint32_t first = tk.k * base + (tk.k < rem ? tk.k : rem);
-    const uint32_t len = base + (tk.k < rem ? 1u : 0u);
-    const uint32_t* e = entries + offset[tk.g] + first;
+  const uint32_t M = offset[nb];
+  const uint32_t S = msm_seg_len(M, lanes);
+  for (uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x; lane < lanes;
+       lane += gridDim.x * blockDim.x) {
+    uint32_t pos = lane * S;
+    if (pos >= M) break;
+    const uint32_t end = pos + S < M ? pos + S : M;
+    uint32_t g = bucket_of(offset, nb, pos);
+    uint32_t bend = offset[g + 1];
     XYZZ29<LF> acc = XYZZ29<LF>::infinity();
-    // software pipeline: the gather of entry j+1 (a random 64/128-byte HBM read, ~2 us under load)
-    // is in flight while the ~1600 multiply-adds of entry j execute
+    // software pipeline: entries are read two iterations ahead, points one iteration ahead, so
+    // the random 64/128-byte gather of entry j+1 is in flight during the ~1600 multiply-adds of j
     auto fetch = [&](uint32_t en, Affine<F>& raw) {
       const uint32_t idx = en & MSM_IDX_MASK;
       if (idx >= idx_min) {
@@ -71,37 +79,43 @@ __global__ void __launch_bounds__(ACC_THREADS)
         raw = Affine<F>::infinity();  // entry below this query's range (public inputs of L)
       }
     };
-    // entries are read two iterations ahead, points one iteration ahead: neither latency is exposed
-    uint32_t en_next = len ? e[0] : 0u;
-    uint32_t en_next2 = len > 1 ? e[1] : 0u;
+    uint32_t en_next = entries[pos];
+    uint32_t en_next2 = pos + 1 < end ? entries[pos + 1] : 0u;
     Affine<F> raw_next = Affine<F>::infinity();
-    if (len) fetch(en_next, raw_next);
-    for (uint32_t j = 0; j < len; ++j) {
-      // consume what the previous iteration fetched, THEN issue the next fetches, THEN compute:
-      // all waits happen on loads that have had a whole madd to complete
+    fetch(en_next, raw_next);
+    for (; pos < end; ++pos) {
+      if (pos == bend) {  // crossed into the next non-empty bucket: emit, restart
+        partial[g + lane] = acc;
+        acc = XYZZ29<LF>::infinity();
+        do {
+          ++g;
+          bend = offset[g + 1];
+        } while (bend == pos);
+      }
       const uint32_t en = en_next;
       Aff29<LF> p = load_packed_affine<F>(raw_next);
       if (en >> 31) p.y = p.y.neg().carry();
       en_next = en_next2;
-      if (j + 2 < len) en_next2 = e[j + 2];
-      if (j + 1 < len) fetch(en_next, raw_next);
+      if (pos + 2 < end) en_next2 = entries[pos + 2];
+      if (pos + 1 < end) fetch(en_next, raw_next);
       acc.madd(p);
     }
-    partial[t] = acc;
+    partial[g + lane] = acc;
   }
 }
 
-// buckets split into 2..MSM_SMALL_MULTI tasks: one thread sums the partials into the first slot
-template <class F>
-__global__ void __launch_bounds__(COMB_THREADS)
-    k_combine_small(uint32_t nb, const uint32_t* __restrict__ ntask_off, MsmAcc<F>* partial) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= nb) return;
-  const uint32_t first = ntask_off[g], nt = ntask_off[g + 1] - first;
-  if (nt < 2 || nt > (uint32_t)MSM_SMALL_MULTI) return;
-  MsmAcc<F> acc = partial[first];
-  for (uint32_t k = 1; k < nt; ++k) acc.add(partial[first + k]);
-  partial[first] = acc;
+// bucket g's partials live in slots [g + first_lane, g + last_lane]
+__device__ __forceinline__ void bucket_slots(const uint32_t* __restrict__ offset, uint32_t g,
+                                             uint32_t S, uint32_t* first, uint32_t* n) {
+  const uint32_t lo = offset[g], hi = offset[g + 1];
+  if (hi == lo) {
+    *first = 0;
+    *n = 0;
+    return;
+  }
+  const uint32_t l0 = lo / S, l1 = (hi - 1) / S;
+  *first = g + l0;
+  *n = l1 - l0 + 1;
 }
 
 // block-wide tree sum through LDS; result valid in thread 0
@@ -123,17 +137,19 @@ __device__ __forceinline__ MsmAcc<F> block_sum(MsmAcc<F> v, MsmAcc<F>* sh) {
   return r;
 }
 
-// hot buckets (> MSM_SMALL_MULTI partials): a whole workgroup per bucket
+// hot buckets (> MSM_SMALL_MULTI partials): a whole workgroup per bucket sums into the first slot
 template <class F>
 __global__ void __launch_bounds__(COMB_THREADS)
     k_combine_large(const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
-                    const uint32_t* __restrict__ ntask_off, MsmAcc<F>* partial) {
+                    const uint32_t* __restrict__ offset, uint32_t nb, uint32_t lanes,
+                    MsmAcc<F>* partial) {
   G16_DYN_SMEM(smem_raw);
   MsmAcc<F>* sh = reinterpret_cast<MsmAcc<F>*>(smem_raw);
   const uint32_t n = meta[1];
+  const uint32_t S = msm_seg_len(offset[nb], lanes);
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint32_t g = list[i];
-    const uint32_t first = ntask_off[g], nt = ntask_off[g + 1] - first;
+    uint32_t first, nt;
+    bucket_slots(offset, list[i], S, &first, &nt);
     MsmAcc<F> acc = MsmAcc<F>::infinity();
     for (uint32_t k = threadIdx.x; k < nt; k += COMB_THREADS) acc.add(partial[first + k]);
     MsmAcc<F> tot = block_sum<F, COMB_THREADS>(acc, sh);
@@ -145,19 +161,22 @@ __global__ void __launch_bounds__(COMB_THREADS)
 // contribution of buckets [lo, lo+L) of one set: sum (b+1) S_b = sum (b-lo+1) S_b + lo * sum S_b
 template <class F>
 __global__ void __launch_bounds__(64)
-    k_bucket_reduce(const MsmAcc<F>* __restrict__ partial, const uint32_t* __restrict__ ntask_off,
-                    uint32_t B, uint32_t chunks_per_set, uint32_t nchunks, MsmAcc<F>* contrib) {
+    k_bucket_reduce(const MsmAcc<F>* __restrict__ partial, const uint32_t* __restrict__ offset,
+                    uint32_t nb, uint32_t lanes, uint32_t B, uint32_t chunks_per_set,
+                    uint32_t nchunks, MsmAcc<F>* contrib) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nchunks) return;
+  const uint32_t S = msm_seg_len(offset[nb], lanes);
   const uint32_t set = q / chunks_per_set;
   const uint32_t lo = (q % chunks_per_set) * (uint32_t)MSM_RED_CHUNK;
   uint32_t hi = lo + MSM_RED_CHUNK;
   if (hi > B) hi = B;
   MsmAcc<F> run = MsmAcc<F>::infinity(), acc = MsmAcc<F>::infinity();
   for (uint32_t b = hi; b-- > lo;) {
-    const uint32_t g = set * B + b;
-    const uint32_t first = ntask_off[g];
-    if (ntask_off[g + 1] != first) run.add(partial[first]);
+    uint32_t first, nt;
+    bucket_slots(offset, set * B + b, S, &first, &nt);
+    if (nt > (uint32_t)MSM_SMALL_MULTI) nt = 1;  // pre-summed into the first slot by k_combine_large
+    for (uint32_t k = 0; k < nt; ++k) run.add(partial[first + k]);
     acc.add(run);
   }
   if (lo != 0 && !run.is_inf()) {
@@ -229,8 +248,8 @@ void MsmPoints<F>::init(const Affine<F>* host_points, uint32_t n, const MsmConfi
 }
 
 template <class F>
-void MsmWork<F>::init(uint32_t max_tasks, uint32_t n_contrib, int max_sets) {
-  partial.alloc(max_tasks ? max_tasks : 1);
+void MsmWork<F>::init(uint32_t n_slots, uint32_t n_contrib, int max_sets) {
+  partial.alloc(n_slots ? n_slots : 1);
   contrib.alloc(n_contrib ? n_contrib : 1);
   bsum.alloc((size_t)256 * max_sets);
   wsum.alloc(max_sets);
@@ -242,33 +261,23 @@ void msm_run(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<
   const MsmConfig& cfg = s.cfg;
   const uint32_t nb = cfg.nb();
   const int acc_stage = sizeof(F) == sizeof(Fq) ? ST_MSM_ACC_G1 : ST_MSM_ACC_G2;
-  // enough workgroups to fill 256 CUs several times over; tasks are grid-strided
-  uint32_t grid = ceil_div(s.max_tasks, ACC_THREADS);
-  static const uint32_t grid_cap = [] {
-    const char* e = getenv("G16_ACC_GRID");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? (uint32_t)v : 8192u;
-  }();
-  if (grid > grid_cap) grid = grid_cap;
-  if (grid < 1) grid = 1;
+  // persistent grid: cfg.lanes lanes, each owning an equal segment of the sorted entry list
+  const uint32_t grid = cfg.lanes / ACC_THREADS;
   int id = tm ? tm->begin(acc_stage, stream) : -1;
-  G16_LAUNCH((k_bucket_accumulate<F>), grid, ACC_THREADS, 0, stream,
-             (const Affine<F>*)P.pts.p, P.count, idx_min, (const uint32_t*)s.entries.p,
-             (const uint32_t*)s.offset.p, (const uint32_t*)s.count.p, (const MsmTask*)s.tasks.p,
-             (const uint32_t*)s.ntask_off.p, nb, work.partial.p);
+  G16_LAUNCH((k_bucket_accumulate<F>), grid, ACC_THREADS, 0, stream, (const Affine<F>*)P.pts.p,
+             P.count, idx_min, (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb,
+             cfg.lanes, work.partial.p);
   if (tm) tm->end(id, stream);
 
   id = tm ? tm->begin(ST_MSM_REDUCE, stream) : -1;
-  G16_LAUNCH((k_combine_small<F>), ceil_div(nb, COMB_THREADS), COMB_THREADS, 0, stream, nb,
-             (const uint32_t*)s.ntask_off.p, work.partial.p);
   G16_LAUNCH((k_combine_large<F>), 1024, COMB_THREADS, COMB_THREADS * sizeof(MsmAcc<F>), stream,
              (const uint32_t*)s.multi_l.p, (const uint32_t*)s.meta.p,
-             (const uint32_t*)s.ntask_off.p, work.partial.p);
+             (const uint32_t*)s.offset.p, nb, cfg.lanes, work.partial.p);
   const uint32_t cps = ceil_div(cfg.B, MSM_RED_CHUNK);
   const uint32_t nchunks = cps * (uint32_t)cfg.D;
   G16_LAUNCH((k_bucket_reduce<F>), ceil_div(nchunks, 64), 64, 0, stream,
-             (const MsmAcc<F>*)work.partial.p, (const uint32_t*)s.ntask_off.p, cfg.B, cps, nchunks,
-             work.contrib.p);
+             (const MsmAcc<F>*)work.partial.p, (const uint32_t*)s.offset.p, nb, cfg.lanes, cfg.B, cps,
+             nchunks, work.contrib.p);
   // two-level tree: cps contributions -> nblk block sums -> 1 per set
   uint32_t nblk = ceil_div(cps, SUM_THREADS * 2);
   if (nblk > 256) nblk = 256;

@@ -11,11 +11,19 @@ namespace g16 {
 
 MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
   MsmConfig cfg;
-  int lg = 0;
-  while (((size_t)1 << (lg + 1)) <= len) ++lg;
-  int c = lg - 2;
-  if (c < 3) c = 3;
-  if (c > 21) c = 21;
+  // window size from a cost model: len * W(c) mixed additions in the bucket kernel plus ~8
+  // mixed-addition equivalents per bucket in the reduction (measured at n = 2^22: c = 20 beats 19,
+  // 21 and 22; profiles/r01_window_sweep.txt)
+  int c = 3;
+  double best = 1e300;
+  for (int t = 3; t <= 22; ++t) {
+    const double Wt = (double)((255 + t - 1) / t);
+    const double cost = (double)len * Wt + 8.0 * (double)((size_t)1 << (t - 1));
+    if (cost < best) {
+      best = cost;
+      c = t;
+    }
+  }
   if (c_override > 0) c = c_override;
   if (c < 2) c = 2;
   if (c > 24) c = 24;
@@ -27,9 +35,9 @@ MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
   cfg.D = (cfg.W + pn - 1) / pn;
   cfg.Pn = (cfg.W + cfg.D - 1) / cfg.D;
   cfg.B = 1u << (c - 1);
-  if (const char* e = getenv("G16_MSM_CHUNK")) {
+  if (const char* e = getenv("G16_ACC_GRID")) {
     const int v = atoi(e);
-    if (v >= 8 && v <= 4096) cfg.chunk = (uint32_t)v;
+    if (v >= 1 && v <= 65536) cfg.lanes = (uint32_t)v * MSM_ACC_THREADS;
   }
   return cfg;
 }
@@ -305,17 +313,18 @@ void scan_exclusive(const uint32_t* in, uint32_t L, int mode, uint32_t* out, uin
   G16_LAUNCH(k_scan_apply, nblk, SCAN_T, 0, s, in, L, mode, (const uint32_t*)tmp, out, out2);
 }
 
-__global__ void __launch_bounds__(256) k_task_fill(const uint32_t* ntask_off, uint32_t nb,
-                                                   MsmTask* tasks, uint32_t* multi_s,
-                                                   uint32_t* multi_l, uint32_t* meta) {
+// buckets whose entries span more than MSM_SMALL_MULTI lane segments (hot buckets of a skewed
+// witness): listed for k_combine_large.  Rare, so the atomics do not matter.
+__global__ void __launch_bounds__(256) k_find_large(const uint32_t* offset, uint32_t nb,
+                                                    uint32_t lanes, uint32_t* multi_l,
+                                                    uint32_t* meta) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
-  const uint32_t first = ntask_off[g];
-  const uint32_t nt = ntask_off[g + 1] - first;
-  for (uint32_t k = 0; k < nt; ++k) tasks[first + k] = MsmTask{g, k};
-  // hot buckets are rare: list them (atomics).  Buckets with 2..MSM_SMALL_MULTI tasks are the
-  // common case with small chunks: k_combine_small visits every bucket instead of a list.
-  if (nt > (uint32_t)MSM_SMALL_MULTI) multi_l[atomicAdd(&meta[1], 1u)] = g;
+  const uint32_t lo = offset[g], hi = offset[g + 1];
+  if (hi == lo) return;
+  const uint32_t S = msm_seg_len(offset[nb], lanes);
+  const uint32_t np = (hi - 1) / S - lo / S + 1;
+  if (np > (uint32_t)MSM_SMALL_MULTI) multi_l[atomicAdd(&meta[1], 1u)] = g;
 }
 
 }  // namespace
@@ -338,20 +347,16 @@ void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   count.alloc((size_t)nb + 1);
   offset.alloc((size_t)nb + 1);
   cursor.alloc((size_t)nb + 1);
-  ntask_off.alloc((size_t)nb + 1);
   entries.alloc(M ? M : 1);
-  const uint64_t nonempty = M < nb ? M : nb;
-  max_tasks = (uint32_t)(M / cfg.chunk + nonempty + 1);
-  tasks.alloc(max_tasks);
-  multi_s.alloc((size_t)(M / (cfg.chunk + 1)) + 2);
-  multi_l.alloc((size_t)(M / ((uint64_t)cfg.chunk * MSM_SMALL_MULTI + 1)) + 2);
+  // a bucket is 'large' when it spans > MSM_SMALL_MULTI segments of >= MSM_MIN_SEG entries
+  multi_l.alloc((size_t)(M / ((uint64_t)MSM_MIN_SEG * MSM_SMALL_MULTI)) + 2);
   meta.alloc(4);
   scan_tmp.alloc(ceil_div((uint64_t)nb + 1, SCAN_TILE) + 1);
 }
 
 size_t MsmSort::device_bytes() const {
-  return part.bytes() + count.bytes() + offset.bytes() + cursor.bytes() + ntask_off.bytes() +
-         entries.bytes() + tasks.bytes() + multi_s.bytes() + multi_l.bytes();
+  return part.bytes() + count.bytes() + offset.bytes() + cursor.bytes() + entries.bytes() +
+         multi_l.bytes();
 }
 
 void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
@@ -393,9 +398,8 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
   scan_exclusive(count.p, nb, 0, offset.p, cursor.p, scan_tmp.p, s);
   G16_LAUNCH(k_bucket_scatter, grid2, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, cursor.p,
              entries.p);
-  scan_exclusive(count.p, nb, (int)cfg.chunk, ntask_off.p, nullptr, scan_tmp.p, s);
-  G16_LAUNCH(k_task_fill, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)ntask_off.p, nb, tasks.p,
-             multi_s.p, multi_l.p, meta.p);
+  G16_LAUNCH(k_find_large, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)offset.p, nb, cfg.lanes,
+             multi_l.p, meta.p);
 }
 
 }  // namespace g16

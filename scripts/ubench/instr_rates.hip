@@ -49,6 +49,41 @@ DEF_KERNEL(k_alignbit, uint32_t, (t + k), (uint64_t)acc[k], "v_alignbit_b32 %0, 
 DEF_KERNEL(k_pk_mul_lo_u16, uint32_t, (t + k), (uint64_t)acc[k], "v_pk_mul_lo_u16 %0, %0, %1", "+v"(acc[k]) : "v"(y))
 DEF_KERNEL(k_pk_mad_u16, uint32_t, (t + k), (uint64_t)acc[k], "v_pk_mad_u16 %0, %0, %1, %0", "+v"(acc[k]) : "v"(y))
 
+DEF_KERNEL(k_ashrrev_i64, uint64_t, (uint64_t)(t + k) * 0x9e3779b97f4a7c15ull, (acc[k]), "v_ashrrev_i64 %0, 1, %0", "+v"(acc[k]))
+DEF_KERNEL(k_lshrrev_b64, uint64_t, (uint64_t)(t + k) * 0x9e3779b97f4a7c15ull, (acc[k]), "v_lshrrev_b64 %0, 1, %0", "+v"(acc[k]))
+DEF_KERNEL(k_mad_i64_i32, uint64_t, (uint64_t)(t + k), (acc[k]), "v_mad_i64_i32 %0, vcc, %1, %2, %0", "+v"(acc[k]) : "v"(x), "v"(y) : "vcc")
+DEF_KERNEL(k_and_b32, uint32_t, (t + k), (uint64_t)acc[k], "v_and_b32 %0, %0, %1", "+v"(acc[k]) : "v"(y))
+DEF_KERNEL(k_sub_u32, uint32_t, (t + k), (uint64_t)acc[k], "v_sub_u32 %0, %0, %1", "+v"(acc[k]) : "v"(y))
+DEF_KERNEL(k_ashrrev_i32, uint32_t, (t + k), (uint64_t)acc[k], "v_ashrrev_i32 %0, 1, %0", "+v"(acc[k]))
+DEF_KERNEL(k_lshl_or_b32, uint32_t, (t + k), (uint64_t)acc[k], "v_lshl_or_b32 %0, %0, 3, %1", "+v"(acc[k]) : "v"(y))
+DEF_KERNEL(k_and_or_b32, uint32_t, (t + k), (uint64_t)acc[k], "v_and_or_b32 %0, %0, %1, %1", "+v"(acc[k]) : "v"(y))
+DEF_KERNEL(k_bfe_u32, uint32_t, (t + k), (uint64_t)acc[k], "v_bfe_u32 %0, %0, 3, 29", "+v"(acc[k]))
+DEF_KERNEL(k_add_lshl_u32, uint32_t, (t + k), (uint64_t)acc[k], "v_add_lshl_u32 %0, %0, %1, 1", "+v"(acc[k]) : "v"(y))
+DEF_KERNEL(k_mad_u64_u32_sgpr, uint64_t, (uint64_t)(t + k), (acc[k]), "v_mad_u64_u32 %0, vcc, %1, s8, %0", "+v"(acc[k]) : "v"(x) : "vcc", "s8")
+
+// mixes: 1 mad + n cheap ops on DIFFERENT registers (do the cheap ops hide behind the mads?)
+#define MIX_KERNEL(NAME, NCHEAP)                                                          \
+  __global__ void __launch_bounds__(THREADS) NAME(uint64_t* out, uint32_t iters, uint32_t seed) { \
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;                            \
+    uint64_t acc[UNROLL];                                                                 \
+    uint32_t c[UNROLL];                                                                   \
+    uint32_t x = t * 2654435761u + seed, y = (t ^ 0x5bd1e995u) | 1u;                      \
+    for (int k = 0; k < UNROLL; ++k) { acc[k] = t + k; c[k] = t ^ k; }                    \
+    for (uint32_t i = 0; i < iters; ++i) {                                                \
+      _Pragma("unroll") for (int k = 0; k < UNROLL; ++k) {                                \
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[k]) : "v"(x), "v"(y) : "vcc"); \
+        _Pragma("unroll") for (int j = 0; j < NCHEAP; ++j)                                \
+          asm volatile("v_and_b32 %0, %0, %1" : "+v"(c[(k + j) % UNROLL]) : "v"(y));       \
+      }                                                                                   \
+    }                                                                                     \
+    uint64_t s = 0;                                                                       \
+    for (int k = 0; k < UNROLL; ++k) s += acc[k] + c[k];                                  \
+    out[t] = s;                                                                           \
+  }
+MIX_KERNEL(k_mix_mad_1and, 1)
+MIX_KERNEL(k_mix_mad_2and, 2)
+MIX_KERNEL(k_mix_mad_4and, 4)
+
 // dependent chain latency: one accumulator
 __global__ void __launch_bounds__(64) k_lat_mad(uint64_t* out, uint32_t iters) {
   uint64_t acc = threadIdx.x;
@@ -83,6 +118,10 @@ int main() {
                 {"v_mul_u32_u24", k_mul_u32_u24}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24},
                 {"v_mad_u32_u24", k_mad_u32_u24}, {"v_mad_i32_i24", k_mad_i32_i24},
                 {"v_pk_mul_lo_u16", k_pk_mul_lo_u16}, {"v_pk_mad_u16", k_pk_mad_u16},
+                {"v_ashrrev_i64", k_ashrrev_i64}, {"v_lshrrev_b64", k_lshrrev_b64}, {"v_mad_i64_i32", k_mad_i64_i32}, {"v_mad_u64_u32(sgpr op)", k_mad_u64_u32_sgpr},
+                {"v_and_b32", k_and_b32}, {"v_sub_u32", k_sub_u32}, {"v_ashrrev_i32", k_ashrrev_i32}, {"v_lshl_or_b32", k_lshl_or_b32},
+                {"v_and_or_b32", k_and_or_b32}, {"v_bfe_u32", k_bfe_u32}, {"v_add_lshl_u32", k_add_lshl_u32},
+                {"mix: 1 mad + 1 and (per mad)", k_mix_mad_1and}, {"mix: 1 mad + 2 and (per mad)", k_mix_mad_2and}, {"mix: 1 mad + 4 and (per mad)", k_mix_mad_4and},
                 {"v_fma_f32", k_fma_f32}, {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64}};
   const uint32_t iters = 4096;
   printf("%-28s %12s %14s %s\n", "instruction", "ms", "Ginstr/s/lane", "cycles/wave-instr/SIMD @2.4GHz");
