@@ -132,6 +132,14 @@ def main():
     stages = prover.stage_times()
     prover.set_profiling(False)
     info = prover.info()
+    # PCIe-inclusive variant (host witness -> H2D inside the call): reported beside, never as `value`
+    host_ms = None
+    if world == 1:
+        prover.prove(rs[0], rs[1], w)
+        t1 = time.perf_counter()
+        for _ in range(2):
+            prover.prove(rs[0], rs[1], w)
+        host_ms = (time.perf_counter() - t1) / 2 * 1e3
 
     if rank != 0:
         if dist:
@@ -178,30 +186,47 @@ def main():
     per_launch_ms = acc_ms / max(acc_cnt, 1)
     # one G1 MSM of length L = 96 L algorithmic bytes (64 B point + 32 B scalar)
     shard_w, shard_h = info["shard_w"], info["shard_h"]
-    avg_len = (3 * shard_w + shard_h) / 4.0
+    avg_len = (3 * shard_w + shard_h) / 4.0          # launches per step: A, B1, L (witness) and H
     alg_bytes = 96.0 * avg_len
     achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        t = json.load(open(tpath))
+        if t.get("log2_domain") == k:
+            traffic = t["traffic_bytes_per_launch"]
     roofline = {"bound": "hbm", "kernel": "k_bucket_accumulate<Fq>", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "avg_launch_ms": per_launch_ms, "launches_per_step": acc_cnt / args.steps,
+                "traffic": traffic, "traffic_unit": "bytes per launch (PMC: profiles/pmc_traffic.json)",
+                "avg_launch_ms": per_launch_ms, "launches_per_step": acc_cnt / args.steps,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "MSM is integer-ALU bound (254-bit Montgomery on v_mad_u64_u32), see DESIGN.md"}
+                "note": "the kernel is integer-ALU bound (254-bit Montgomery arithmetic on v_mad_i64_i32), "
+                        "not HBM bound: see `alu` and DESIGN.md section 4-5"}
+    # supplementary: the same launches against the micro-benchmarked integer multiply-add issue peak
+    W_w, W_h = info["W_w"], info["W_h"]
+    madds = (3 * shard_w * W_w + shard_h * W_h) / 4.0          # mixed additions per launch (upper bound)
+    VMAD_PER_MADD = 1557.0                                     # 8 products + 2 squarings on 9x29-bit limbs
+    VMAD_PEAK = 30.1e12                                        # profiles/r01_instr_rates.txt
+    alu = {"kernel": "k_bucket_accumulate<Fq>", "mixed_additions_per_s": madds / (per_launch_ms * 1e-3),
+           "vmad_per_s": madds * VMAD_PER_MADD / (per_launch_ms * 1e-3), "vmad_peak_per_s": VMAD_PEAK,
+           "frac": madds * VMAD_PER_MADD / (per_launch_ms * 1e-3) / VMAD_PEAK,
+           "alu_only_ceiling_mixed_additions_per_s": 16.7e9}
 
     ms_per_step = elapsed / args.steps * 1e3
     out = {
         "metric": "Groth16 constraints/sec (BN254)", "value": m * args.steps / elapsed,
         "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery)",
+        "scaling": "strong", "vs_baseline": None, "dtype": "int32x9 (29-bit limbs of 254-bit Montgomery integers)",
         "data": "synthetic",
         "config": {"workload": f"synthetic squaring-chain R1CS, 2^{k}-2 constraints, BN254, full prove "
                                "(witness map + 4 G1 MSM + 1 G2 MSM + finalize), trapdoor key minted on GPU",
                    "log2_domain": k, "num_constraints": m, "n_vars": n_vars,
                    "parallelism": f"msm-point-range-shard x{world}" if world > 1 else "single-gpu",
                    "msm": info},
-        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "alu": alu, "cpu_baseline": cpu, "parity": parity,
         "stages_ms_per_step": {n: ms / args.steps for n, (ms, _c) in stages.items()},
-        "setup_s": t_setup,
+        "setup_s": t_setup, "ms_per_step_with_host_witness_upload": host_ms,
     }
     if cpu:
         out["gpu_over_cpu"] = out["value"] / cpu["value"]

@@ -40,7 +40,8 @@ struct g16_ctx {
   MsmWork<Fq> work1;
   MsmWork<Fq2> work2;
 
-  DevBuf<Fr> w_dev, h_dev, rs_dev;
+  DevBuf<Fr> w_dev, h_dev, rs_dev;  // h_dev: storage form (g16_witness_map / g16_msm_g1 staging)
+  DevBuf<U256> h_canon;             // h as canonical integers: scalars of the H-query MSM
   DevBuf<KeyHeaderDev> key_dev;
   DevBuf<ProofSums> sums_dev;
   DevBuf<FinTables> fin_tab;
@@ -117,10 +118,10 @@ void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
   G16_HIP(hipEventRecord(c->ev_w, s));  // w is resident (upload enqueued on the main stream)
   G16_HIP(hipStreamWaitEvent(x, c->ev_w, 0));
   int id = tm ? tm->begin(ST_WITNESS_NTT, x) : -1;
-  c->wm.run(w_dev, c->h_dev.p, x);
+  c->wm.run(w_dev, c->h_canon.p, nullptr, x);
   if (tm) tm->end(id, x);
   id = tm ? tm->begin(ST_MSM_SORT, x) : -1;
-  c->sort_h.run(c->h_dev.p + c->h_lo, c->h_hi - c->h_lo, /*mont=*/true, x);
+  c->sort_h.run(c->h_canon.p + c->h_lo, c->h_hi - c->h_lo, /*mont=*/false, x);
   if (tm) tm->end(id, x);
   G16_HIP(hipEventRecord(c->ev_h, x));
 
@@ -215,6 +216,7 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
 
     c->w_dev.alloc(c->N);
     c->h_dev.alloc(c->n);
+    c->h_canon.alloc(c->n);
     c->has_key = key->a_query != nullptr;
     if (!c->has_key) {
       G16_HIP(hipStreamSynchronize(s));
@@ -317,7 +319,7 @@ g16_status g16_witness_map(g16_ctx* c, const uint64_t* w, size_t n_vars, uint64_
   return guarded(c, [&]() -> g16_status {
     hipStream_t s = c->stream;
     G16_HIP(hipMemcpyAsync(c->w_dev.p, w, (size_t)c->N * 32, hipMemcpyHostToDevice, s));
-    c->wm.run(c->w_dev.p, c->h_dev.p, s);
+    c->wm.run(c->w_dev.p, nullptr, c->h_dev.p, s);
     G16_HIP(hipMemcpyAsync(h_out, c->h_dev.p, (size_t)c->n * 32, hipMemcpyDeviceToHost, s));
     G16_HIP(hipStreamSynchronize(s));
     return G16_OK;
@@ -515,7 +517,7 @@ g16_status g16_ctx_info(const g16_ctx* c, uint32_t out[16]) {
   out[0] = c->cfg_w.c; out[1] = c->cfg_w.W; out[2] = c->cfg_w.Pn; out[3] = c->cfg_w.D;
   out[4] = c->cfg_h.c; out[5] = c->cfg_h.W; out[6] = c->cfg_h.Pn; out[7] = c->cfg_h.D;
   out[8] = c->n;
-  out[9] = (uint32_t)c->wm.plan.k;
+  out[9] = (uint32_t)c->wm.plan.base.k;
   out[10] = c->w_hi - c->w_lo;
   out[11] = c->h_hi - c->h_lo;
   return G16_OK;
@@ -542,10 +544,28 @@ g16_status g16_debug_ntt(int device, uint64_t* data, int log_n, int inverse, int
       ntt_dif(plan, a.p, n, 1, inverse != 0, inverse ? NTT_FUSE_SCALE : NTT_FUSE_NONE, nullptr);
       bitrev_copy(a.p, b.p, log_n, nullptr);
       res = b.p;
-    } else {
+    } else if (algo == 1) {
       if (inverse) return fail(nullptr, G16_ERR_INVALID, "algo 1 (DIT) is forward-only");
       bitrev_copy(a.p, b.p, log_n, nullptr);
       ntt_dit(plan, b.p, n, 1, false, nullptr);
+      res = b.p;
+    } else {  // 2: lazy-limb DIF + bit reversal, 3: bit reversal + lazy-limb DIT (forward only)
+      if (algo == 3 && inverse) return fail(nullptr, G16_ERR_INVALID, "algo 3 (DIT) is forward-only");
+      Ntt29Plan p29;
+      p29.build(log_n, nullptr);
+      DevBuf<int32_t> pa, pb;
+      pa.alloc((size_t)NTT29_LIMBS * n);
+      pb.alloc((size_t)NTT29_LIMBS * n);
+      ntt29_to_planes(a.p, pa.p, n, nullptr);
+      if (algo == 2) {
+        ntt29_dif(p29, pa.p, (size_t)NTT29_LIMBS * n, 1, inverse != 0,
+                  inverse ? NTT_FUSE_SCALE : NTT_FUSE_NONE, nullptr);
+        ntt29_bitrev_planes(pa.p, pb.p, log_n, nullptr);
+      } else {
+        ntt29_bitrev_planes(pa.p, pb.p, log_n, nullptr);
+        ntt29_dit(p29, pb.p, (size_t)NTT29_LIMBS * n, 1, nullptr);
+      }
+      ntt29_from_planes(pb.p, b.p, n, nullptr);
       res = b.p;
     }
     G16_HIP(hipDeviceSynchronize());

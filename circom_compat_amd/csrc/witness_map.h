@@ -2,7 +2,7 @@
 // (reference src/circom/qap.rs:23-88).  The CSR matrices are the A and B of the reference's
 // ConstraintMatrices (src/zkey.rs:151-196): row-major sparse rows of (coeff, index).
 #pragma once
-#include "ntt.h"
+#include "ntt29.h"
 
 namespace g16 {
 
@@ -24,13 +24,16 @@ struct CsrStore {
 
 struct WitnessMap {
   uint32_t m = 0, num_inputs = 0, n = 0;
-  NttPlan plan;
+  Ntt29Plan plan;
   CsrStore dA, dB;
-  DevBuf<Fr> abc;  // a | b | c, n elements each
+  DevBuf<int32_t> abc;  // a | b | c as limb planes (ntt29.h): [3][9][n] int32
 
   void init(const CsrHost& A, const CsrHost& B, uint32_t m, uint32_t num_inputs);
-  // w_dev: full assignment (>= max column index + 1 elements, Montgomery); h_dev: n elements out
-  void run(const Fr* w_dev, Fr* h_dev, hipStream_t stream);
+  // w_dev: full assignment (>= max column index + 1 elements, Montgomery).
+  // h_canon (optional): h as canonical integers (ark-ff into_bigint form) -- what the H-query MSM
+  //                     consumes; h_mont (optional): h in the storage form (Montgomery), the value
+  //                     CircomReduction::witness_map_from_matrices returns.
+  void run(const Fr* w_dev, U256* h_canon, Fr* h_mont, hipStream_t stream);
 };
 
 }  // namespace g16

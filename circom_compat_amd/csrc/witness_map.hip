@@ -3,8 +3,8 @@
 // Follows reference src/circom/qap.rs:23-88 step for step:
 //   :37-58  a = A.w, b = B.w (rows >= m: a gets the first num_inputs witness values), c = a o b
 //           -> k_spmv_abc (one pass, c fused)
-//   :60-61,69-70,79-80  ifft + distribute_powers(omega_2n) -> ntt_dif(inverse, TWIST_SCALE), batch of 3
-//   :72-73,81           fft                                 -> ntt_dit, batch of 3
+//   :60-61,69-70,79-80  ifft + distribute_powers(omega_2n) -> ntt29_dif(inverse, TWIST_SCALE), batch of 3
+//   :72-73,81           fft                                 -> ntt29_dit, batch of 3
 //   :75,83-85           ab - c                              -> k_mul_sub
 // Results are field elements, so they are bit-identical to the reference whatever the schedule.
 #include "witness_map.h"
@@ -30,8 +30,7 @@ __device__ __forceinline__ Fr row_dot(const uint32_t* rowptr, const uint32_t* co
 }
 
 __global__ void __launch_bounds__(256) k_spmv_abc(CsrDev A, CsrDev B, const Fr* w, uint32_t m,
-                                                  uint32_t num_inputs, uint32_t n, Fr* a, Fr* b,
-                                                  Fr* c) {
+                                                  uint32_t num_inputs, uint32_t n, int32_t* abc) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fr ai = Fr::zero(), bi = Fr::zero(), ci = Fr::zero();
@@ -42,16 +41,35 @@ __global__ void __launch_bounds__(256) k_spmv_abc(CsrDev A, CsrDev B, const Fr* 
   } else if (i < m + num_inputs) {
     ai = w[i - m];  // qap.rs:46-50
   }
-  a[i] = ai;
-  b[i] = bi;
-  c[i] = ci;
+  // hand over to the NTT in its own layout: lazy limbs, one plane per limb
+  const size_t vs = (size_t)NTT29_LIMBS * n;
+  store_planes(abc, n, i, Fr29::from_mont256(ai));
+  store_planes(abc + vs, n, i, Fr29::from_mont256(bi));
+  store_planes(abc + 2 * vs, n, i, Fr29::from_mont256(ci));
 }
 
-__global__ void __launch_bounds__(256) k_mul_sub(const Fr* a, const Fr* b, const Fr* c, Fr* h,
+// h = a * b - c (qap.rs:75,83-85), written as canonical integers and / or in the storage form
+__global__ void __launch_bounds__(256) k_mul_sub(const int32_t* abc, U256* h_canon, Fr* h_mont,
                                                  uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  h[i] = a[i] * b[i] - c[i];
+  const size_t vs = (size_t)NTT29_LIMBS * n;
+  const Fr29 one = Fr29::one();
+  const Fr29 a = load_planes(abc, n, i) * one;  // forward-NTT outputs are < 24 r: bring one factor below 2 r
+  const Fr29 b = load_planes(abc + vs, n, i);
+  const Fr29 c = load_planes(abc + 2 * vs, n, i);
+  const Fr29 h = Fr29::mul2(a, b, c.neg(), one);
+  if (h_mont) h_mont[i] = h.to_mont256();
+  if (h_canon) {
+    // internal value x * 2^261 -> the integer x: one Montgomery reduction (multiplication by the
+    // integer 1), then the unique representative in [0, r)
+    f29::L9 uno{};
+    uno.v[0] = 1;
+    const Fr29 x = (h * Fr29::from_limbs(uno)).canonical();
+    U256 u;
+    x.pack(u.v);
+    h_canon[i] = u;
+  }
 }
 
 }  // namespace
@@ -64,8 +82,8 @@ void WitnessMap::init(const CsrHost& A, const CsrHost& B, uint32_t m_, uint32_t 
   while (((uint64_t)1 << k) < need) ++k;
   // qap.rs:31,66: both the size-n and the size-2n domain must exist (Fr two-adicity 28)
   if (k + 1 > 28) throw std::runtime_error("PolynomialDegreeTooLarge");
-  plan.build(k);
-  n = (uint32_t)plan.n;
+  plan.build(k, nullptr);
+  n = (uint32_t)plan.n();
   auto up = [&](const CsrHost& h, CsrStore& d) {
     d.rowptr.alloc((size_t)m + 1);
     d.col.alloc(h.nnz ? h.nnz : 1);
@@ -78,20 +96,17 @@ void WitnessMap::init(const CsrHost& A, const CsrHost& B, uint32_t m_, uint32_t 
   };
   up(A, dA);
   up(B, dB);
-  abc.alloc((size_t)3 * n);
+  abc.alloc((size_t)3 * NTT29_LIMBS * n);
 }
 
-void WitnessMap::run(const Fr* w_dev, Fr* h_dev, hipStream_t stream) {
-  Fr* a = abc.p;
-  Fr* b = abc.p + n;
-  Fr* c = abc.p + 2 * (size_t)n;
+void WitnessMap::run(const Fr* w_dev, U256* h_canon, Fr* h_mont, hipStream_t stream) {
   CsrDev A{dA.rowptr.p, dA.col.p, dA.val.p};
   CsrDev B{dB.rowptr.p, dB.col.p, dB.val.p};
-  G16_LAUNCH(k_spmv_abc, ceil_div(n, 256), 256, 0, stream, A, B, w_dev, m, num_inputs, n, a, b, c);
-  ntt_dif(plan, abc.p, n, 3, /*inverse=*/true, NTT_FUSE_TWIST_SCALE, stream);
-  ntt_dit(plan, abc.p, n, 3, /*inverse=*/false, stream);
-  G16_LAUNCH(k_mul_sub, ceil_div(n, 256), 256, 0, stream, (const Fr*)a, (const Fr*)b,
-             (const Fr*)c, h_dev, n);
+  const size_t vs = (size_t)NTT29_LIMBS * n;
+  G16_LAUNCH(k_spmv_abc, ceil_div(n, 256), 256, 0, stream, A, B, w_dev, m, num_inputs, n, abc.p);
+  ntt29_dif(plan, abc.p, vs, 3, /*inverse=*/true, NTT_FUSE_TWIST_SCALE, stream);
+  ntt29_dit(plan, abc.p, vs, 3, stream);
+  G16_LAUNCH(k_mul_sub, ceil_div(n, 256), 256, 0, stream, (const int32_t*)abc.p, h_canon, h_mont, n);
 }
 
 }  // namespace g16

@@ -135,7 +135,9 @@ void* g16_witness_buffer(g16_ctx* ctx);
 
 /* ---- debug / parity entry points (tests) ----------------------------------------------------- */
 /* In-place size-2^log_n NTT of host data, natural order in and out (ark-poly fft_in_place /
- * ifft_in_place semantics).  algo 0: DIF kernels + bit-reversal; algo 1: bit-reversal + DIT.      */
+ * ifft_in_place semantics).  algo 0: DIF kernels + bit-reversal; algo 1: bit-reversal + DIT
+ * (saturated-limb kernels of ntt.hip, used by the key generator); algo 2 / 3: the same two
+ * schedules on the lazy-limb kernels of ntt29.hip (the witness map's).                             */
 g16_status g16_debug_ntt(int device, uint64_t* data, int log_n, int inverse, int algo);
 
 /* Integer-ALU ceilings (measurement only): kind 0 = Fq Montgomery multiplications, 1 = raw

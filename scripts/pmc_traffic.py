@@ -1,0 +1,42 @@
+"""Derive per-launch HBM traffic of the dominant kernel from the PMC passes (scripts/pmc_passes.sh) and
+write profiles/pmc_traffic.json, which bench.py reports as roofline.traffic.
+
+Read requests are sized by the L2's own request-size counters (TCC_EA0_RDREQ_32B/_64B/_128B; the remaining
+requests are counted as 64 B), which sidesteps the FETCH_SIZE calibration caveat of MI355X_MICROARCH.md
+(FETCH_SIZE = RDREQ x 64 B under-reports 128-byte requests); FETCH_SIZE / WRITE_SIZE (KB) are kept beside it.
+
+    python scripts/pmc_traffic.py gpurun_out/pmc22 22 profiles/pmc_traffic.json
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def main(root, log2, out):
+    acc = defaultdict(list)
+    for path in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if "k_bucket_accumulate<g16::Fp<" in row["Kernel_Name"]:
+                    acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    m = {k: sum(v) / len(v) for k, v in acc.items()}
+    rd, r32, r64, r128 = (m.get(k, 0.0) for k in ("TCC_EA0_RDREQ", "TCC_EA0_RDREQ_32B", "TCC_EA0_RDREQ_64B", "TCC_EA0_RDREQ_128B"))
+    other = max(rd - r32 - r64 - r128, 0.0)
+    read_bytes = 32 * r32 + 64 * (r64 + other) + 128 * r128
+    wr, w64 = m.get("TCC_EA0_WRREQ", 0.0), m.get("TCC_EA0_WRREQ_64B", 0.0)
+    write_bytes = 64 * w64 + 32 * max(wr - w64, 0.0)
+    rec = {"kernel": "k_bucket_accumulate<Fq>", "log2_domain": int(log2), "launches_averaged": len(acc.get("TCC_EA0_RDREQ", [])),
+           "read_bytes_per_launch": read_bytes, "write_bytes_per_launch": write_bytes,
+           "traffic_bytes_per_launch": read_bytes + write_bytes,
+           "fetch_size_kb": m.get("FETCH_SIZE"), "write_size_kb": m.get("WRITE_SIZE"),
+           "counters": m, "source": "rocprofv3 --pmc, scripts/pmc_passes.sh (separate passes), " + root}
+    with open(out, "w") as f:
+        json.dump(rec, f, indent=1)
+    print(json.dumps({k: rec[k] for k in ("read_bytes_per_launch", "write_bytes_per_launch", "fetch_size_kb", "write_size_kb")}))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3])

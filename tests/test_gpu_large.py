@@ -25,6 +25,9 @@ def test_ntt_vs_oracle_large(gpulib, k):
     assert H.fr_from_mont_arr(_ntt(gpulib, arr, k, False, 0)) == o.ntt(x)
     assert H.fr_from_mont_arr(_ntt(gpulib, arr, k, True, 0)) == o.ntt(x, inverse=True)
     assert H.fr_from_mont_arr(_ntt(gpulib, arr, k, False, 1)) == o.ntt(x)
+    assert H.fr_from_mont_arr(_ntt(gpulib, arr, k, False, 2)) == o.ntt(x)
+    assert H.fr_from_mont_arr(_ntt(gpulib, arr, k, True, 2)) == o.ntt(x, inverse=True)
+    assert H.fr_from_mont_arr(_ntt(gpulib, arr, k, False, 3)) == o.ntt(x)
 
 
 @pytest.mark.parametrize("k", [20, 22])
@@ -38,6 +41,9 @@ def test_ntt_properties_full_size(gpulib, k):
     f0 = _ntt(gpulib, arr, k, False, 0)
     f1 = _ntt(gpulib, arr, k, False, 1)
     assert np.array_equal(f0, f1)
+    assert np.array_equal(f0, _ntt(gpulib, arr, k, False, 2))     # lazy-limb DIF
+    assert np.array_equal(f0, _ntt(gpulib, arr, k, False, 3))     # lazy-limb DIT
+    assert np.array_equal(arr, _ntt(gpulib, f0, k, True, 2))
     back = _ntt(gpulib, f0, k, True, 0)
     assert np.array_equal(back, arr)
     # delta at position j -> X[i] = omega^(i*j): check a few entries against the oracle

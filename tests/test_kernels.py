@@ -32,6 +32,21 @@ def test_ntt_vs_oracle(lib, k):
     assert _ntt(lib, x, False, 0) == o.ntt(x)
     assert _ntt(lib, x, True, 0) == o.ntt(x, inverse=True)
     assert _ntt(lib, x, False, 1) == o.ntt(x)
+    # the witness map's own kernels (lazy 29-bit limbs, limb planes): algo 2 = DIF, 3 = DIT
+    assert _ntt(lib, x, False, 2) == o.ntt(x)
+    assert _ntt(lib, x, True, 2) == o.ntt(x, inverse=True)
+    assert _ntt(lib, x, False, 3) == o.ntt(x)
+
+
+def test_ntt_lazy_limbs_edge_values(lib):
+    """all-zero, all (r-1) and a single spike: the value-drift bookkeeping of ntt29.hip is exercised at
+    its extremes (the emulator build asserts the limb / value bounds on every product)"""
+    k = 11
+    n = 1 << k
+    for x in ([0] * n, [o.R_MOD - 1] * n, [1] + [0] * (n - 1), [o.R_MOD - 1 if i % 2 else 1 for i in range(n)]):
+        assert _ntt(lib, x, False, 2) == o.ntt(x)
+        assert _ntt(lib, x, True, 2) == o.ntt(x, inverse=True)
+        assert _ntt(lib, x, False, 3) == o.ntt(x)
 
 
 def test_ntt_small_matches_naive_dft(lib):
