@@ -381,13 +381,17 @@ class Prover:
                                               C.c_void_p(w_dev_ptr), self.n_vars, _np_ptr(out)), self.ctx)
         return Proof(out.tobytes())
 
-    def prove_partial(self, full_assignment=None, w_dev_ptr: Optional[int] = None) -> bytes:
+    def prove_partial(self, r, s, full_assignment=None, w_dev_ptr: Optional[int] = None) -> bytes:
+        """this rank's G16_PARTIAL_BYTES record: its A, B1, B2, L, H sums and s*A, r*B1"""
+        rs = _as_fr([r, s], self.lib) if not isinstance(r, np.ndarray) else np.stack([r, s])
         out = np.empty(B.G16_PARTIAL_BYTES, dtype=np.uint8)
         if w_dev_ptr is not None:
-            st = self.lib.g16_prove_partial_dev(self.ctx, C.c_void_p(w_dev_ptr), self.n_vars, _np_ptr(out))
+            st = self.lib.g16_prove_partial_dev(self.ctx, _np_ptr(rs[0:1]), _np_ptr(rs[1:2]),
+                                                C.c_void_p(w_dev_ptr), self.n_vars, _np_ptr(out))
         else:
             w = _as_fr(full_assignment, self.lib)
-            st = self.lib.g16_prove_partial(self.ctx, _np_ptr(w), w.shape[0], _np_ptr(out))
+            st = self.lib.g16_prove_partial(self.ctx, _np_ptr(rs[0:1]), _np_ptr(rs[1:2]), _np_ptr(w),
+                                            w.shape[0], _np_ptr(out))
         self.lib.check(st, self.ctx)
         return out.tobytes()
 

@@ -11,6 +11,8 @@
 #include "msm.h"
 #include "witness_map.h"
 
+static_assert(G16_PARTIAL_BYTES == g16::FIN_PARTIAL_BYTES, "partial record size out of sync");
+
 using namespace g16;
 
 namespace {
@@ -428,14 +430,26 @@ g16_status g16_prove(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], cons
   return g16_prove_dev(c, r, s_, c->w_dev.p, n_vars, proof_out);
 }
 
-g16_status g16_prove_partial_dev(g16_ctx* c, const void* w_dev, size_t n_vars,
+g16_status g16_prove_partial_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4],
+                                 const void* w_dev, size_t n_vars,
                                  uint8_t partial_out[G16_PARTIAL_BYTES]) {
-  if (!c || !w_dev || !partial_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (!c || !r || !s_ || !w_dev || !partial_out) return fail(c, G16_ERR_INVALID, "null argument");
   if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
   if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
   return guarded(c, [&]() -> g16_status {
     hipStream_t s = c->stream;
-    run_msms(c, (const Fr*)w_dev);
+    uint64_t rs[8];
+    memcpy(rs, r, 32);
+    memcpy(rs + 4, s_, 32);
+    G16_HIP(hipMemcpyAsync(c->rs_dev.p, rs, 64, hipMemcpyHostToDevice, s));
+    run_msms(c, (const Fr*)w_dev, [&] {
+      // this rank's s*A and r*B1 (variable-base, one wave each) overlap its L / B2 / H MSMs
+      G16_HIP(hipEventRecord(c->ev_ab, s));
+      G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
+      fin_partial_var(c->sums_dev.p, c->rs_dev.p, c->side);
+      G16_HIP(hipEventRecord(c->ev_side, c->side));
+    });
+    G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));
     uint8_t* part = c->out_dev.p + G16_PROOF_BYTES;
     sums_to_partial(c->sums_dev.p, part, s);
     G16_HIP(hipMemcpyAsync(partial_out, part, G16_PARTIAL_BYTES, hipMemcpyDeviceToHost, s));
@@ -445,7 +459,8 @@ g16_status g16_prove_partial_dev(g16_ctx* c, const void* w_dev, size_t n_vars,
   });
 }
 
-g16_status g16_prove_partial(g16_ctx* c, const uint64_t* w, size_t n_vars,
+g16_status g16_prove_partial(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4],
+                             const uint64_t* w, size_t n_vars,
                              uint8_t partial_out[G16_PARTIAL_BYTES]) {
   if (!c || !w) return fail(c, G16_ERR_INVALID, "null argument");
   if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
@@ -454,7 +469,7 @@ g16_status g16_prove_partial(g16_ctx* c, const uint64_t* w, size_t n_vars,
     return G16_OK;
   });
   if (st != G16_OK) return st;
-  return g16_prove_partial_dev(c, c->w_dev.p, n_vars, partial_out);
+  return g16_prove_partial_dev(c, r, s_, c->w_dev.p, n_vars, partial_out);
 }
 
 g16_status g16_prove_finish(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4],
@@ -473,9 +488,8 @@ g16_status g16_prove_finish(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4
     G16_HIP(hipMemcpyAsync(gathered, partials, (size_t)world * G16_PARTIAL_BYTES,
                            hipMemcpyHostToDevice, s));
     partials_to_sums(gathered, world, c->sums_dev.p, s);
-    fin_fixed(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, s);
-    fin_var(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->fin_scr.p, c->out_dev.p, s);
-    fin_final(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, s);
+    fin_fixed_dist(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, s);
+    fin_final_dist(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, s);
     G16_HIP(hipMemcpyAsync(proof_out, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
     G16_HIP(hipStreamSynchronize(s));
     return G16_OK;

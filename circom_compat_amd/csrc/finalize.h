@@ -31,17 +31,21 @@ struct KeyHeaderDev {  // device-resident copy of the O(1) key points (storage f
 struct ProofSums {  // MSM outputs (device), lazy internal form
   G1XYZZ29 A, B1, L, H;
   G2XYZZ29 B2;
+  G1XYZZ29 sA, rB1;  // sharded provers only: s * A and r * B1 of this rank's shard
 };
 
-struct FinTables {  // per key: 2^i * delta1, 2^i * delta2, i < 256
-  G1XYZZ29 d1[256];
-  G2XYZZ29 d2[256];
+struct FinTables {  // per key: 2^i * P, i < 256, for the fixed bases of the finalisation
+  G1XYZZ29 d1[256];  // delta1
+  G2XYZZ29 d2[256];  // delta2
+  G1XYZZ29 ta[256];  // a_query[0] + alpha1
+  G1XYZZ29 tb[256];  // b_g1_query[0] + beta1
 };
 
 struct FinScratch {  // per proof
   G1XYZZ29 rd1, sd1, rsd1;  // r*delta1, s*delta1, rs*delta1
   G2XYZZ29 sd2;             // s*delta2
   G1XYZZ29 sga, rgb;        // s*g_a, r*g1_b
+  G1XYZZ29 sta, rtb;        // s*(a0 + alpha1), r*(b1_0 + beta1)   (sharded provers)
 };
 
 void fin_build_tables(const KeyHeaderDev* key, FinTables* tab, hipStream_t stream);
@@ -51,9 +55,20 @@ void fin_var(const KeyHeaderDev* key, const ProofSums* sums, const Fr* rs_dev, F
 void fin_final(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr,
                uint8_t* proof_dev, hipStream_t stream);
 
-// ProofSums -> 384-byte affine record A|B1|B2|L|H in the storage form (one rank's contribution)
+// ---- sharded provers (one process per GPU) ----------------------------------------------------
+// The variable-base products of the finalisation are linear in the MSM sums, so every rank
+// multiplies ITS partial sums while its remaining MSMs run:
+//   s*g_a = s*r*delta1 + s*(a0 + alpha1) + sum_ranks s*A_rank        (and likewise r*g1_b)
+// which leaves only fixed-base products (table tree-sums) and three affine conversions after the
+// all-gather.
+void fin_partial_var(ProofSums* sums, const Fr* rs_dev, hipStream_t stream);  // sA, rB1 from A, B1
+void fin_fixed_dist(const FinTables* tab, const Fr* rs_dev, FinScratch* scr, hipStream_t stream);
+void fin_final_dist(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr,
+                    uint8_t* proof_dev, hipStream_t stream);
+constexpr int FIN_PARTIAL_BYTES = 512;  // A | B1 | B2 | L | H | sA | rB1, affine, storage form
+// ProofSums -> one rank's 512-byte record
 void sums_to_partial(const ProofSums* sums, uint8_t* partial_dev, hipStream_t stream);
-// world x 384-byte records -> ProofSums (local EC adds: the "all-reduce" tail)
+// world x 512-byte records -> ProofSums (local EC adds: the "all-reduce" tail)
 void partials_to_sums(const uint8_t* partials_dev, int world, ProofSums* sums, hipStream_t stream);
 
 }  // namespace g16

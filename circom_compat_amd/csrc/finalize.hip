@@ -32,21 +32,34 @@ __device__ __forceinline__ Affine<F> to_storage_affine(const XYZZ29<typename Laz
   return Affine<F>{p.x.to_mont256(), p.y.to_mont256()};
 }
 
-// block 0: G1 table, block 1: G2 table; thread 0 doubles 255 times (ctx-create only)
+// one block per table; thread 0 doubles 255 times (ctx-create only)
 __global__ void k_fin_tables(const KeyHeaderDev* key, FinTables* tab) {
   if (threadIdx.x != 0) return;
-  if (blockIdx.x == 0) {
-    G1XYZZ29 q = G1XYZZ29::from_affine(affine_from_mont256<Fq>(key->delta1));
-    for (int i = 0; i < 256; ++i) {
-      tab->d1[i] = q;
-      q.dbl_in_place();
-    }
-  } else {
+  if (blockIdx.x == 1) {
     G2XYZZ29 q = G2XYZZ29::from_affine(affine_from_mont256<Fq2>(key->delta2));
     for (int i = 0; i < 256; ++i) {
       tab->d2[i] = q;
       q.dbl_in_place();
     }
+    return;
+  }
+  G1XYZZ29 q;
+  G1XYZZ29* dst;
+  if (blockIdx.x == 0) {
+    q = G1XYZZ29::from_affine(affine_from_mont256<Fq>(key->delta1));
+    dst = tab->d1;
+  } else if (blockIdx.x == 2) {
+    q = G1XYZZ29::from_affine(affine_from_mont256<Fq>(key->a0));
+    q.madd(affine_from_mont256<Fq>(key->alpha1));
+    dst = tab->ta;
+  } else {
+    q = G1XYZZ29::from_affine(affine_from_mont256<Fq>(key->b1_0));
+    q.madd(affine_from_mont256<Fq>(key->beta1));
+    dst = tab->tb;
+  }
+  for (int i = 0; i < 256; ++i) {
+    dst[i] = q;
+    q.dbl_in_place();
   }
 }
 
@@ -131,31 +144,112 @@ __global__ void __launch_bounds__(64) k_fin_final(const KeyHeaderDev* key, const
   }
 }
 
-__global__ void __launch_bounds__(64) k_sums_to_partial(const ProofSums* sums, uint8_t* out) {
+// ---- sharded provers ---------------------------------------------------------------------------
+// block 0: sA = s * A      block 1: rB1 = r * B1     (this rank's partial sums)
+__global__ void __launch_bounds__(64) k_fin_partial_var(ProofSums* sums, const Fr* rs) {
+  __shared__ G1XYZZ29 tbl[16];
   if (threadIdx.x != 0) return;
-  switch (blockIdx.x) {
-    case 0: *reinterpret_cast<G1Affine*>(out) = to_storage_affine<Fq>(sums->A); break;
-    case 1: *reinterpret_cast<G1Affine*>(out + 64) = to_storage_affine<Fq>(sums->B1); break;
-    case 2: *reinterpret_cast<G1Affine*>(out + 256) = to_storage_affine<Fq>(sums->L); break;
-    case 3: *reinterpret_cast<G1Affine*>(out + 320) = to_storage_affine<Fq>(sums->H); break;
-    default: *reinterpret_cast<G2Affine*>(out + 128) = to_storage_affine<Fq2>(sums->B2); break;
+  if (blockIdx.x == 0) sums->sA = var_mul(sums->A, rs[1].to_canonical(), tbl);
+  else sums->rB1 = var_mul(sums->B1, rs[0].to_canonical(), tbl);
+}
+
+// blocks 0..2: k * delta1 (k = r, s, rs); 3: s * delta2; 4: s * (a0 + alpha1); 5: r * (b1_0 + beta1)
+__global__ void __launch_bounds__(FIN_T) k_fin_fixed_dist(const FinTables* tab, const Fr* rs,
+                                                          FinScratch* scr) {
+  G16_DYN_SMEM(smem_raw);
+  const int t = threadIdx.x;
+  const Fr r = rs[0], s = rs[1];
+  const int b = blockIdx.x;
+  const U256 k = (b == 0 || b == 5 ? r : (b == 2 ? r * s : s)).to_canonical();
+  if (b == 3) {
+    G2XYZZ29* sh = reinterpret_cast<G2XYZZ29*>(smem_raw);
+    G2XYZZ29 v = G2XYZZ29::infinity();
+    if (bit_of(k, t)) v = tab->d2[t];
+    if (bit_of(k, t + FIN_T)) v.add(tab->d2[t + FIN_T]);
+    G2XYZZ29 tot = tree_sum(v, sh);
+    if (t == 0) scr->sd2 = tot;
+    return;
   }
+  const G1XYZZ29* base = b <= 2 ? tab->d1 : (b == 4 ? tab->ta : tab->tb);
+  G1XYZZ29* sh = reinterpret_cast<G1XYZZ29*>(smem_raw);
+  G1XYZZ29 v = G1XYZZ29::infinity();
+  if (bit_of(k, t)) v = base[t];
+  if (bit_of(k, t + FIN_T)) v.add(base[t + FIN_T]);
+  G1XYZZ29 tot = tree_sum(v, sh);
+  if (t == 0) {
+    G1XYZZ29* dst = b == 0 ? &scr->rd1 : (b == 1 ? &scr->sd1 : (b == 2 ? &scr->rsd1 : (b == 4 ? &scr->sta : &scr->rtb)));
+    *dst = tot;
+  }
+}
+
+// block 0: A      block 1: B      block 2: C   (sums already reduced over the ranks)
+__global__ void __launch_bounds__(64) k_fin_final_dist(const KeyHeaderDev* key, const ProofSums* sums,
+                                                       const FinScratch* scr, uint8_t* proof) {
+  if (threadIdx.x != 0) return;
+  if (blockIdx.x == 0) {
+    G1XYZZ29 a = scr->rd1;
+    a.madd(affine_from_mont256<Fq>(key->a0));
+    a.add(sums->A);
+    a.madd(affine_from_mont256<Fq>(key->alpha1));
+    *reinterpret_cast<G1Affine*>(proof) = to_storage_affine<Fq>(a);
+  } else if (blockIdx.x == 1) {
+    G2XYZZ29 b = scr->sd2;
+    b.madd(affine_from_mont256<Fq2>(key->b2_0));
+    b.add(sums->B2);
+    b.madd(affine_from_mont256<Fq2>(key->beta2));
+    *reinterpret_cast<G2Affine*>(proof + 64) = to_storage_affine<Fq2>(b);
+  } else {
+    // g_c = s g_a + r g1_b - rs delta1 + L + H with s g_a = rs delta1 + s (a0 + alpha1) + s A, ...
+    G1XYZZ29 c = sums->sA;
+    c.add(sums->rB1);
+    c.add(scr->sta);
+    c.add(scr->rtb);
+    c.add(scr->rsd1);
+    c.add(sums->L);
+    c.add(sums->H);
+    *reinterpret_cast<G1Affine*>(proof + 192) = to_storage_affine<Fq>(c);
+  }
+}
+
+__device__ __forceinline__ G1XYZZ29* g1_sum_slot(ProofSums* s, int b) {
+  switch (b) {
+    case 0: return &s->A;
+    case 1: return &s->B1;
+    case 2: return &s->L;
+    case 3: return &s->H;
+    case 4: return &s->sA;
+    default: return &s->rB1;
+  }
+}
+__device__ __forceinline__ int g1_sum_offset(int b) {  // byte offset inside a partial record
+  const int off[6] = {0, 64, 256, 320, 384, 448};
+  return off[b];
+}
+
+// blocks 0..5: the six G1 sums, block 6: B2
+__global__ void __launch_bounds__(64) k_sums_to_partial(ProofSums* sums, uint8_t* out) {
+  if (threadIdx.x != 0) return;
+  const int b = blockIdx.x;
+  if (b < 6) *reinterpret_cast<G1Affine*>(out + g1_sum_offset(b)) = to_storage_affine<Fq>(*g1_sum_slot(sums, b));
+  else *reinterpret_cast<G2Affine*>(out + 128) = to_storage_affine<Fq2>(sums->B2);
 }
 
 __global__ void __launch_bounds__(64) k_partials_to_sums(const uint8_t* parts, int world,
                                                          ProofSums* sums) {
   if (threadIdx.x != 0) return;
   const int b = blockIdx.x;
-  if (b < 4) {
-    const int off = b == 0 ? 0 : (b == 1 ? 64 : (b == 2 ? 256 : 320));
+  if (b < 6) {
+    const int off = g1_sum_offset(b);
     G1XYZZ29 acc = G1XYZZ29::infinity();
     for (int k = 0; k < world; ++k)
-      acc.madd(affine_from_mont256<Fq>(*reinterpret_cast<const G1Affine*>(parts + (size_t)k * 384 + off)));
-    (b == 0 ? sums->A : (b == 1 ? sums->B1 : (b == 2 ? sums->L : sums->H))) = acc;
+      acc.madd(affine_from_mont256<Fq>(
+          *reinterpret_cast<const G1Affine*>(parts + (size_t)k * FIN_PARTIAL_BYTES + off)));
+    *g1_sum_slot(sums, b) = acc;
   } else {
     G2XYZZ29 acc = G2XYZZ29::infinity();
     for (int k = 0; k < world; ++k)
-      acc.madd(affine_from_mont256<Fq2>(*reinterpret_cast<const G2Affine*>(parts + (size_t)k * 384 + 128)));
+      acc.madd(affine_from_mont256<Fq2>(
+          *reinterpret_cast<const G2Affine*>(parts + (size_t)k * FIN_PARTIAL_BYTES + 128)));
     sums->B2 = acc;
   }
 }
@@ -163,7 +257,7 @@ __global__ void __launch_bounds__(64) k_partials_to_sums(const uint8_t* parts, i
 }  // namespace
 
 void fin_build_tables(const KeyHeaderDev* key, FinTables* tab, hipStream_t stream) {
-  G16_LAUNCH(k_fin_tables, 2, 64, 0, stream, key, tab);
+  G16_LAUNCH(k_fin_tables, 4, 64, 0, stream, key, tab);
 }
 void fin_fixed(const FinTables* tab, const Fr* rs_dev, FinScratch* scr, hipStream_t stream) {
   G16_LAUNCH(k_fin_fixed, 4, FIN_T, FIN_T * sizeof(G2XYZZ29), stream, tab, rs_dev, scr);
@@ -176,11 +270,21 @@ void fin_final(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch*
                uint8_t* proof_dev, hipStream_t stream) {
   G16_LAUNCH(k_fin_final, 2, 64, 0, stream, key, sums, scr, proof_dev);
 }
+void fin_partial_var(ProofSums* sums, const Fr* rs_dev, hipStream_t stream) {
+  G16_LAUNCH(k_fin_partial_var, 2, 64, 0, stream, sums, rs_dev);
+}
+void fin_fixed_dist(const FinTables* tab, const Fr* rs_dev, FinScratch* scr, hipStream_t stream) {
+  G16_LAUNCH(k_fin_fixed_dist, 6, FIN_T, FIN_T * sizeof(G2XYZZ29), stream, tab, rs_dev, scr);
+}
+void fin_final_dist(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr,
+                    uint8_t* proof_dev, hipStream_t stream) {
+  G16_LAUNCH(k_fin_final_dist, 3, 64, 0, stream, key, sums, scr, proof_dev);
+}
 void sums_to_partial(const ProofSums* sums, uint8_t* partial_dev, hipStream_t stream) {
-  G16_LAUNCH(k_sums_to_partial, 5, 64, 0, stream, sums, partial_dev);
+  G16_LAUNCH(k_sums_to_partial, 7, 64, 0, stream, const_cast<ProofSums*>(sums), partial_dev);
 }
 void partials_to_sums(const uint8_t* partials_dev, int world, ProofSums* sums, hipStream_t stream) {
-  G16_LAUNCH(k_partials_to_sums, 5, 64, 0, stream, partials_dev, world, sums);
+  G16_LAUNCH(k_partials_to_sums, 7, 64, 0, stream, partials_dev, world, sums);
 }
 
 }  // namespace g16

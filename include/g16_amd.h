@@ -75,7 +75,7 @@ typedef struct {
 } g16_options;
 
 #define G16_PROOF_BYTES 256   /* A(64) | B(128) | C(64), affine */
-#define G16_PARTIAL_BYTES 384 /* A(64) | B1(64) | B2(128) | L(64) | H(64): one rank's MSM sums */
+#define G16_PARTIAL_BYTES 512 /* A | B1 | B2(128) | L | H | s*A | r*B1: one rank's sums (affine) */
 
 enum { G16_QUERY_A = 0, G16_QUERY_B1 = 1, G16_QUERY_L = 2, G16_QUERY_H = 3 };
 
@@ -110,13 +110,16 @@ g16_status g16_prove(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4], con
 g16_status g16_prove_dev(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4], const void* w_dev,
                          size_t n_vars, uint8_t proof_out[G16_PROOF_BYTES]);
 
-/* Multi-GPU (one process per GPU): every rank computes the sums of ITS point range, the host
- * framework all-gathers the G16_PARTIAL_BYTES records (RCCL all_gather; EC addition is not an
- * ncclRedOp, so "all-reduce" = all-gather + local add), then any rank finishes the proof.
- * partials: world x G16_PARTIAL_BYTES in rank order.                                              */
-g16_status g16_prove_partial(g16_ctx* ctx, const uint64_t* w, size_t n_vars,
+/* Multi-GPU (one process per GPU): every rank computes the sums of ITS point range -- and, while
+ * its remaining MSMs run, the two products s*A_rank and r*B1_rank the finalisation is linear in --
+ * the host framework all-gathers the G16_PARTIAL_BYTES records (RCCL all_gather; EC addition is
+ * not an ncclRedOp, so "all-reduce" = all-gather + local add), then any rank finishes the proof
+ * with fixed-base table sums only.  partials: world x G16_PARTIAL_BYTES in rank order.             */
+g16_status g16_prove_partial(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4],
+                             const uint64_t* w, size_t n_vars,
                              uint8_t partial_out[G16_PARTIAL_BYTES]);
-g16_status g16_prove_partial_dev(g16_ctx* ctx, const void* w_dev, size_t n_vars,
+g16_status g16_prove_partial_dev(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4],
+                                 const void* w_dev, size_t n_vars,
                                  uint8_t partial_out[G16_PARTIAL_BYTES]);
 g16_status g16_prove_finish(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4],
                             const uint8_t* partials, int world, uint8_t proof_out[G16_PROOF_BYTES]);

@@ -33,9 +33,9 @@ WORKER = textwrap.dedent('''
     pk = H.pk_from_oracle(opk)
     r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
     pr = cc.Prover(pk, mats, lib=lib, rank=rank, world=world)
-    part = pr.prove_partial(w)
+    part = pr.prove_partial(r, s, w)
     mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
-    gathered = torch.empty(world * 384, dtype=torch.uint8)
+    gathered = torch.empty(world * 512, dtype=torch.uint8)
     dist.all_gather_into_tensor(gathered, mine)
     proof = pr.prove_finish(r, s, gathered.numpy().tobytes())
     want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2, len(cons), w)

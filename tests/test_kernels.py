@@ -197,7 +197,7 @@ def test_prove_synthetic_circuit_vs_oracle(lib):
     parts = b""
     for rank in range(2):
         p2 = cc.Prover(pk, mats, lib=lib, rank=rank, world=2)
-        parts += p2.prove_partial(w)
+        parts += p2.prove_partial(r, s, w)
     assert p2.prove_finish(r, s, parts).raw == proof.raw
 
 
