@@ -91,8 +91,9 @@ def main():
     rng = random.Random(k)
     tox = [rng.randrange(1, R_MOD) for _ in range(5)]
     pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox, device=local_rank)
+    dist_wm = world > 1 and os.environ.get("G16_BENCH_DIST_WM", "1") != "0"
     prover = cc.Prover(pk, mats, device=local_rank, rank=rank, world=world,
-                       window_bits=args.window_bits, planes=args.planes)
+                       window_bits=args.window_bits, planes=args.planes, dist_wm=dist_wm)
     w = cc.fr_from_ints(w_ints)
     rs_rng = random.Random(1000 + k)
     r, s = rs_rng.randrange(R_MOD), rs_rng.randrange(R_MOD)
@@ -102,13 +103,31 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
-    gathered = torch.empty(world * 512, dtype=torch.uint8, device=f"cuda:{local_rank}") if world > 1 else None
+    dev = f"cuda:{local_rank}"
+    gathered = torch.empty(world * 512, dtype=torch.uint8, device=dev) if world > 1 else None
+    if dist_wm:
+        nbytes = prover.exchange_bytes()
+        send = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        recv = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+    def exchange():
+        # RCCL all-to-all over xGMI on torch's stream; only that stream is waited for, so the ctx's
+        # own MSM stream keeps running underneath
+        dist.all_to_all_single(recv, send)
+        torch.cuda.current_stream().synchronize()
 
     def step():
         if world == 1:
             return prover.prove_dev(rs[0], rs[1], w_dev.data_ptr())
-        part = prover.prove_partial(rs[0], rs[1], w_dev_ptr=w_dev.data_ptr())
-        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(gathered.device)
+        if dist_wm:
+            prover.dist_phase1(rs[0], rs[1], w_dev.data_ptr(), send.data_ptr())
+            exchange()
+            prover.dist_phase2(recv.data_ptr(), send.data_ptr())
+            exchange()
+            part = prover.dist_phase3(recv.data_ptr())
+        else:
+            part = prover.prove_partial(rs[0], rs[1], w_dev_ptr=w_dev.data_ptr())
+        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
         dist.all_gather_into_tensor(gathered, mine)
         return prover.prove_finish(rs[0], rs[1], gathered.cpu().numpy().tobytes())
 
@@ -240,7 +259,7 @@ def main():
         "config": {"workload": f"synthetic squaring-chain R1CS, 2^{k}-2 constraints, BN254, full prove "
                                "(witness map + 4 G1 MSM + 1 G2 MSM + finalize), trapdoor key minted on GPU",
                    "log2_domain": k, "num_constraints": m, "n_vars": n_vars,
-                   "parallelism": f"msm-point-range-shard x{world}" if world > 1 else "single-gpu",
+                   "parallelism": (f"msm-point-range-shard x{world}" + (" + four-step witness map (2 all-to-all)" if dist_wm else " (witness map replicated)")) if world > 1 else "single-gpu",
                    "msm": info},
         "roofline": roofline, "alu": alu, "cpu_baseline": cpu, "parity": parity,
         "stages_ms_per_step": {n: ms / args.steps for n, (ms, _c) in stages.items()},

@@ -311,7 +311,7 @@ class Prover:
 
     def __init__(self, pk: Optional[ProvingKey], matrices: ConstraintMatrices, device=0, rank=0,
                  world=1, window_bits=0, planes=0, lib: Optional[B.Library] = None,
-                 n_vars: Optional[int] = None):
+                 n_vars: Optional[int] = None, dist_wm=False):
         self.lib = lib or B.load()
         self.matrices = matrices
         self.pk = pk
@@ -331,6 +331,8 @@ class Prover:
         opt = B.Options()
         opt.device, opt.rank, opt.world = device, rank, world
         opt.window_bits, opt.planes = window_bits, planes
+        opt.dist_wm = 1 if (dist_wm and world > 1) else 0
+        self.dist_wm = bool(opt.dist_wm)
         self.rank, self.world = rank, world
         a, b = matrices.a.to_c(), matrices.b.to_c()
         ctx = C.c_void_p()
@@ -393,6 +395,26 @@ class Prover:
             st = self.lib.g16_prove_partial(self.ctx, _np_ptr(rs[0:1]), _np_ptr(rs[1:2]), _np_ptr(w),
                                             w.shape[0], _np_ptr(out))
         self.lib.check(st, self.ctx)
+        return out.tobytes()
+
+    # -- fully sharded prover (dist_wm=True): three phases around two all-to-all exchanges
+    def exchange_bytes(self) -> int:
+        return int(self.lib.g16_dist_exchange_bytes(self.ctx))
+
+    def dist_phase1(self, r, s, w_dev_ptr: int, send_ptr: int):
+        rs = _as_fr([r, s], self.lib) if not isinstance(r, np.ndarray) else np.stack([r, s])
+        self.lib.check(self.lib.g16_prove_dist_phase1(self.ctx, _np_ptr(rs[0:1]), _np_ptr(rs[1:2]),
+                                                      C.c_void_p(w_dev_ptr), self.n_vars,
+                                                      C.c_void_p(send_ptr)), self.ctx)
+
+    def dist_phase2(self, recv_ptr: int, send_ptr: int):
+        self.lib.check(self.lib.g16_prove_dist_phase2(self.ctx, C.c_void_p(recv_ptr),
+                                                      C.c_void_p(send_ptr)), self.ctx)
+
+    def dist_phase3(self, recv_ptr: int) -> bytes:
+        out = np.empty(B.G16_PARTIAL_BYTES, dtype=np.uint8)
+        self.lib.check(self.lib.g16_prove_dist_phase3(self.ctx, C.c_void_p(recv_ptr), _np_ptr(out)),
+                       self.ctx)
         return out.tobytes()
 
     def prove_finish(self, r, s, partials: bytes) -> Proof:

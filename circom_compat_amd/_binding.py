@@ -55,7 +55,8 @@ class KeyDesc(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("device", C.c_int), ("rank", C.c_int), ("world", C.c_int),
-                ("window_bits", C.c_int), ("planes", C.c_int), ("reserved", C.c_int * 3)]
+                ("window_bits", C.c_int), ("planes", C.c_int), ("dist_wm", C.c_int),
+                ("reserved", C.c_int * 2)]
 
 
 class ZkeyHeader(C.Structure):
@@ -84,7 +85,8 @@ class R1csHeader(C.Structure):
 ABI_SYMBOLS = [
     "g16_ctx_create", "g16_ctx_destroy", "g16_last_error", "g16_witness_map", "g16_msm_g1",
     "g16_msm_g2", "g16_prove", "g16_prove_dev", "g16_prove_partial", "g16_prove_partial_dev",
-    "g16_prove_finish", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info",
+    "g16_prove_finish", "g16_dist_exchange_bytes", "g16_prove_dist_phase1", "g16_prove_dist_phase2",
+    "g16_prove_dist_phase3", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info",
     "g16_witness_buffer", "g16_debug_ntt", "g16_debug_alu_bench",
     "g16_setup_create", "g16_setup_destroy", "g16_setup_key",
     "g16_loader_last_error", "g16_zkey_open", "g16_zkey_open_mem", "g16_zkey_close",
@@ -106,6 +108,15 @@ class Library:
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C circom_compat_amd/csrc). "
                 "There is no CPU fallback.")
         self.path = path
+        # PyTorch-ROCm wheels carry their own HIP runtime.  If libg16_amd.so (linked against
+        # /opt/rocm's libamdhip64) is loaded first, a later `import torch` ends up with a second
+        # runtime and reports "No HIP GPUs are available".  Host frameworks that use torch for
+        # device buffers / RCCL therefore get its runtime loaded first; G16_NO_TORCH_PRELOAD=1 skips it.
+        if not os.environ.get("G16_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = self.L = C.CDLL(path)
         vp = C.c_void_p
         sig = {
@@ -121,6 +132,10 @@ class Library:
             "g16_prove_partial": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp]),
             "g16_prove_partial_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp]),
             "g16_prove_finish": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
+            "g16_dist_exchange_bytes": (C.c_size_t, [vp]),
+            "g16_prove_dist_phase1": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp]),
+            "g16_prove_dist_phase2": (C.c_int, [vp, vp, vp]),
+            "g16_prove_dist_phase3": (C.c_int, [vp, vp, vp]),
             "g16_set_profiling": (C.c_int, [vp, C.c_int]),
             "g16_stage_times": (C.c_int, [vp, C.POINTER(C.c_float), _u32p]),
             "g16_stage_name": (C.c_char_p, [C.c_int]),

@@ -10,6 +10,7 @@
 #include "finalize.h"
 #include "msm.h"
 #include "witness_map.h"
+#include "wm_dist.h"
 
 static_assert(G16_PARTIAL_BYTES == g16::FIN_PARTIAL_BYTES, "partial record size out of sync");
 
@@ -32,6 +33,8 @@ struct g16_ctx {
   std::string err;
 
   WitnessMap wm;
+  WmDist wd;             // distributed witness map (options.dist_wm, world > 1)
+  bool dist_wm = false;
   // shard of the assignment-index space [0, N-1) (entry i <-> w[1+i]) and of [0, n) for H
   uint32_t w_lo = 0, w_hi = 0, h_lo = 0, h_hi = 0;
   uint32_t l_idx_min = 0;  // entries below this local index have no L point (public inputs)
@@ -106,17 +109,39 @@ void collect_times(g16_ctx* c) {
   if (c->timer.enabled) c->timer.collect(c->st_ms, c->st_cnt);
 }
 
-// MSMs of one proof on this ctx's shard; results left in sums_dev.  `after_ab` (optional) is
-// called once the A and B1 sums are enqueued: the single-GPU prover forks the variable-base part
-// of the finalisation onto the side stream there.
+// main stream: witness-scalar sort, then the A, B1, L, B2 MSMs (ALU bound).  `after_ab` is called
+// once the A and B1 sums are enqueued: the provers fork the variable-base part of the
+// finalisation onto the side stream there.
+template <class Hook>
+void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
+  hipStream_t s = c->stream;
+  StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
+  ProofSums* S = c->sums_dev.p;
+  int id = tm ? tm->begin(ST_MSM_SORT, s) : -1;
+  c->sort_w.run(w_dev + 1 + c->w_lo, c->w_hi - c->w_lo, /*mont=*/true, s);
+  if (tm) tm->end(id, s);
+  msm_run<Fq>(c->sort_w, c->ptsA, 0, c->work1, &S->A, s, tm);
+  msm_run<Fq>(c->sort_w, c->ptsB1, 0, c->work1, &S->B1, s, tm);
+  after_ab();
+  msm_run<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, &S->L, s, tm);
+  msm_run<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, &S->B2, s, tm);
+}
+
+// main stream: H MSM once the aux stream has produced (and sorted) this rank's h scalars
+void enqueue_h_msm(g16_ctx* c) {
+  hipStream_t s = c->stream;
+  StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
+  G16_HIP(hipStreamWaitEvent(s, c->ev_h, 0));
+  msm_run<Fq>(c->sort_h, c->ptsH, 0, c->work1, &c->sums_dev.p->H, s, tm);
+}
+
+// MSMs of one proof on this ctx's shard; results left in sums_dev.
+// aux stream: witness map (integer-ALU bound) then the H-query sort (atomics/HBM bound), beside
+// the main stream's work.
 template <class Hook>
 void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
   hipStream_t s = c->stream, x = c->overlap ? c->aux : c->stream;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
-  ProofSums* S = c->sums_dev.p;
-  // aux stream: witness map (integer-ALU bound) then the H-query sort (atomics/HBM bound).
-  // main stream: witness-scalar sort, then the A, B1, L, B2 MSMs (ALU bound).  The two streams
-  // pair a memory-bound kernel with an ALU-bound one most of the time.
   G16_HIP(hipEventRecord(c->ev_w, s));  // w is resident (upload enqueued on the main stream)
   G16_HIP(hipStreamWaitEvent(x, c->ev_w, 0));
   int id = tm ? tm->begin(ST_WITNESS_NTT, x) : -1;
@@ -126,18 +151,8 @@ void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
   c->sort_h.run(c->h_canon.p + c->h_lo, c->h_hi - c->h_lo, /*mont=*/false, x);
   if (tm) tm->end(id, x);
   G16_HIP(hipEventRecord(c->ev_h, x));
-
-  id = tm ? tm->begin(ST_MSM_SORT, s) : -1;
-  c->sort_w.run(w_dev + 1 + c->w_lo, c->w_hi - c->w_lo, /*mont=*/true, s);
-  if (tm) tm->end(id, s);
-  msm_run<Fq>(c->sort_w, c->ptsA, 0, c->work1, &S->A, s, tm);
-  msm_run<Fq>(c->sort_w, c->ptsB1, 0, c->work1, &S->B1, s, tm);
-  after_ab();
-  msm_run<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, &S->L, s, tm);
-  msm_run<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, &S->B2, s, tm);
-
-  G16_HIP(hipStreamWaitEvent(s, c->ev_h, 0));
-  msm_run<Fq>(c->sort_h, c->ptsH, 0, c->work1, &S->H, s, tm);
+  enqueue_witness_msms(c, w_dev, after_ab);
+  enqueue_h_msm(c);
 }
 
 void run_msms(g16_ctx* c, const Fr* w_dev) {
@@ -206,14 +221,24 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     c->m = num_constraints;
     CsrHost A{a->row_ptr, a->col, (const Fr*)a->coeff, (size_t)a->nnz};
     CsrHost B{b->row_ptr, b->col, (const Fr*)b->coeff, (size_t)b->nnz};
-    c->wm.init(A, B, c->m, c->num_inputs);
-    c->n = c->wm.n;
+    c->dist_wm = o.dist_wm != 0 && o.world > 1;
+    if (c->dist_wm) {
+      c->wd.init(A, B, c->m, c->num_inputs, c->rank, c->world);
+      c->n = c->wd.n;
+    } else {
+      c->wm.init(A, B, c->m, c->num_inputs);
+      c->n = c->wm.n;
+    }
     if (key->domain_size != c->n)
       throw std::runtime_error("key domain_size does not match num_constraints + num_inputs");
 
     const uint32_t len_w = c->N - 1;
     shard(len_w, c->rank, c->world, &c->w_lo, &c->w_hi);
     shard(c->n, c->rank, c->world, &c->h_lo, &c->h_hi);
+    if (c->dist_wm) {  // the distributed witness map leaves n / world scalars, local order
+      c->h_lo = 0;
+      c->h_hi = c->n / (uint32_t)c->world;
+    }
     const uint32_t lw = c->w_hi - c->w_lo, lh = c->h_hi - c->h_lo;
 
     c->w_dev.alloc(c->N);
@@ -251,7 +276,16 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     }
     c->cfg_h = fit_config(lh ? lh : 1, o.window_bits, o.planes, 64, reserve);
     c->sort_h.init(lh, c->cfg_h);
-    c->ptsH.init((const G1Affine*)key->h_query + c->h_lo, lh, c->cfg_h, s);
+    if (c->dist_wm) {
+      // this rank's h scalars are the evaluations e = global_index(t): gather the matching points
+      std::vector<G1Affine> mine(lh);
+      const G1Affine* hq = (const G1Affine*)key->h_query;
+      for (uint32_t t = 0; t < lh; ++t) mine[t] = hq[c->wd.global_index(t)];
+      c->ptsH.init(mine.data(), lh, c->cfg_h, s);
+      G16_HIP(hipStreamSynchronize(s));  // `mine` is read by the async upload
+    } else {
+      c->ptsH.init((const G1Affine*)key->h_query + c->h_lo, lh, c->cfg_h, s);
+    }
 
     // one workspace per curve, large enough for either sort
     {
@@ -317,6 +351,7 @@ void g16_ctx_destroy(g16_ctx* c) {
 
 g16_status g16_witness_map(g16_ctx* c, const uint64_t* w, size_t n_vars, uint64_t* h_out) {
   if (!c || !w || !h_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->dist_wm) return fail(c, G16_ERR_INVALID, "dist_wm ctx holds 1/world of the witness map");
   if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
   return guarded(c, [&]() -> g16_status {
     hipStream_t s = c->stream;
@@ -436,6 +471,7 @@ g16_status g16_prove_partial_dev(g16_ctx* c, const uint64_t r[4], const uint64_t
   if (!c || !r || !s_ || !w_dev || !partial_out) return fail(c, G16_ERR_INVALID, "null argument");
   if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
   if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+  if (c->dist_wm) return fail(c, G16_ERR_INVALID, "dist_wm ctx: use the g16_prove_dist_phase* calls");
   return guarded(c, [&]() -> g16_status {
     hipStream_t s = c->stream;
     uint64_t rs[8];
@@ -496,6 +532,67 @@ g16_status g16_prove_finish(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4
   });
 }
 
+size_t g16_dist_exchange_bytes(const g16_ctx* c) {
+  return (c && c->dist_wm) ? c->wd.exchange_ints() * sizeof(int32_t) : 0;
+}
+
+g16_status g16_prove_dist_phase1(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4],
+                                 const void* w_dev, size_t n_vars, void* send_dev) {
+  if (!c || !r || !s_ || !w_dev || !send_dev) return fail(c, G16_ERR_INVALID, "null argument");
+  if (!c->dist_wm || !c->has_key) return fail(c, G16_ERR_INVALID, "not a dist_wm proving ctx");
+  if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+  return guarded(c, [&]() -> g16_status {
+    hipStream_t s = c->stream, x = c->aux;
+    uint64_t rs[8];
+    memcpy(rs, r, 32);
+    memcpy(rs + 4, s_, 32);
+    G16_HIP(hipMemcpyAsync(c->rs_dev.p, rs, 64, hipMemcpyHostToDevice, s));
+    G16_HIP(hipEventRecord(c->ev_w, s));
+    G16_HIP(hipStreamWaitEvent(x, c->ev_w, 0));
+    c->wd.phase1((const Fr*)w_dev, (int32_t*)send_dev, x);
+    // the witness-scalar MSMs of this rank's point range run on the main stream during both
+    // exchanges and phases 2-3
+    enqueue_witness_msms(c, (const Fr*)w_dev, [&] {
+      G16_HIP(hipEventRecord(c->ev_ab, s));
+      G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
+      fin_partial_var(c->sums_dev.p, c->rs_dev.p, c->side);
+      G16_HIP(hipEventRecord(c->ev_side, c->side));
+    });
+    G16_HIP(hipStreamSynchronize(x));  // send buffer complete; the main stream keeps running
+    return G16_OK;
+  });
+}
+
+g16_status g16_prove_dist_phase2(g16_ctx* c, const void* recv_dev, void* send_dev) {
+  if (!c || !recv_dev || !send_dev) return fail(c, G16_ERR_INVALID, "null argument");
+  if (!c->dist_wm) return fail(c, G16_ERR_INVALID, "not a dist_wm ctx");
+  return guarded(c, [&]() -> g16_status {
+    c->wd.phase2((const int32_t*)recv_dev, (int32_t*)send_dev, c->aux);
+    G16_HIP(hipStreamSynchronize(c->aux));
+    return G16_OK;
+  });
+}
+
+g16_status g16_prove_dist_phase3(g16_ctx* c, const void* recv_dev,
+                                 uint8_t partial_out[G16_PARTIAL_BYTES]) {
+  if (!c || !recv_dev || !partial_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (!c->dist_wm || !c->has_key) return fail(c, G16_ERR_INVALID, "not a dist_wm proving ctx");
+  return guarded(c, [&]() -> g16_status {
+    hipStream_t s = c->stream, x = c->aux;
+    c->wd.phase3((const int32_t*)recv_dev, c->h_canon.p, x);
+    c->sort_h.run(c->h_canon.p, c->h_hi - c->h_lo, /*mont=*/false, x);
+    G16_HIP(hipEventRecord(c->ev_h, x));
+    enqueue_h_msm(c);
+    G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));
+    uint8_t* part = c->out_dev.p + G16_PROOF_BYTES;
+    sums_to_partial(c->sums_dev.p, part, s);
+    G16_HIP(hipMemcpyAsync(partial_out, part, G16_PARTIAL_BYTES, hipMemcpyDeviceToHost, s));
+    G16_HIP(hipStreamSynchronize(s));
+    collect_times(c);
+    return G16_OK;
+  });
+}
+
 g16_status g16_set_profiling(g16_ctx* c, int enabled) {
   if (!c) return G16_ERR_INVALID;
   c->timer.enabled = enabled != 0;
@@ -531,7 +628,7 @@ g16_status g16_ctx_info(const g16_ctx* c, uint32_t out[16]) {
   out[0] = c->cfg_w.c; out[1] = c->cfg_w.W; out[2] = c->cfg_w.Pn; out[3] = c->cfg_w.D;
   out[4] = c->cfg_h.c; out[5] = c->cfg_h.W; out[6] = c->cfg_h.Pn; out[7] = c->cfg_h.D;
   out[8] = c->n;
-  out[9] = (uint32_t)c->wm.plan.base.k;
+  out[9] = (uint32_t)(c->dist_wm ? c->wd.k : c->wm.plan.base.k);
   out[10] = c->w_hi - c->w_lo;
   out[11] = c->h_hi - c->h_lo;
   return G16_OK;

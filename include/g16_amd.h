@@ -71,7 +71,8 @@ typedef struct {
   int rank, world; /* point-range shard of the MSMs owned by this ctx (world = 1: everything)   */
   int window_bits; /* MSM window c; <= 0: automatic                                              */
   int planes;      /* stored multiples 2^(c*D*j)P per point; <= 0: as many as fit (full = W)     */
-  int reserved[3];
+  int dist_wm;     /* world > 1 only: distribute the witness map too (g16_prove_dist_phase*)      */
+  int reserved[2];
 } g16_options;
 
 #define G16_PROOF_BYTES 256   /* A(64) | B(128) | C(64), affine */
@@ -123,6 +124,21 @@ g16_status g16_prove_partial_dev(g16_ctx* ctx, const uint64_t r[4], const uint64
                                  uint8_t partial_out[G16_PARTIAL_BYTES]);
 g16_status g16_prove_finish(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4],
                             const uint8_t* partials, int world, uint8_t proof_out[G16_PROOF_BYTES]);
+
+/* Fully sharded prover (ctx created with options.dist_wm = 1, world a power of two): the witness map
+ * (CircomReduction::witness_map_from_matrices, src/circom/qap.rs:23-88) is split over the ranks as
+ * four-step NTTs whose two transposes are all-to-all exchanges the host framework performs
+ * (RCCL all_to_all over xGMI) between the three phases.  send/recv: device buffers of
+ * g16_dist_exchange_bytes() bytes, `world` equal chunks in rank order (all_to_all_single layout).
+ *   phase1(r, s, w_dev, send)  -> exchange 1 -> phase2(recv, send) -> exchange 2
+ *   -> phase3(recv, partial_out) -> all-gather of the partial records -> g16_prove_finish.
+ * The rank's A / B1 / L / B2 MSMs run on the ctx's main stream during the exchanges.               */
+size_t g16_dist_exchange_bytes(const g16_ctx* ctx);
+g16_status g16_prove_dist_phase1(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4],
+                                 const void* w_dev, size_t n_vars, void* send_dev);
+g16_status g16_prove_dist_phase2(g16_ctx* ctx, const void* recv_dev, void* send_dev);
+g16_status g16_prove_dist_phase3(g16_ctx* ctx, const void* recv_dev,
+                                 uint8_t partial_out[G16_PARTIAL_BYTES]);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
 #define G16_N_STAGES 8

@@ -1,4 +1,4 @@
-"""world_size = 2 over gloo on the CPU: the sharded path (per-rank point-range MSM partials ->
+"""world_size = 2 and 4 over gloo on the CPU: the sharded path (per-rank point-range MSM partials ->
 all_gather -> local EC add -> finish) gives the same proof bytes as the single-rank path.
 Runs the kernel sources on the SIMT emulator (tests only); on the GPU the same harness code in
 bench.py uses backend nccl (= RCCL)."""
@@ -24,7 +24,7 @@ WORKER = textwrap.dedent('''
     lib = _binding.Library(os.path.join(ROOT, "tests", "emu", "libg16_emu.so"))
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cons, w, n_vars, n_pub = H.squaring_chain(4)
+    cons, w, n_vars, n_pub = H.squaring_chain(int(sys.argv[2]))
     rng = random.Random(42)
     tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
     opk = o.trapdoor_setup(cons, n_vars, n_pub, *tox)
@@ -40,6 +40,21 @@ WORKER = textwrap.dedent('''
     proof = pr.prove_finish(r, s, gathered.numpy().tobytes())
     want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2, len(cons), w)
     assert proof.raw == o.proof_to_bytes(want), "sharded proof differs from the oracle"
+    # fully sharded: the witness map is distributed too (four-step NTTs, two all-to-all exchanges)
+    pd = cc.Prover(pk, mats, lib=lib, rank=rank, world=world, dist_wm=True)
+    nbytes = pd.exchange_bytes()
+    send = torch.empty(nbytes, dtype=torch.uint8)
+    recv = torch.empty(nbytes, dtype=torch.uint8)
+    w_arr = H.fr_mont_arr(w)                      # the emulator's "device" memory is host memory
+    pd.dist_phase1(r, s, w_arr.ctypes.data, send.data_ptr())
+    dist.all_to_all_single(recv, send)
+    pd.dist_phase2(recv.data_ptr(), send.data_ptr())
+    dist.all_to_all_single(recv, send)
+    part2 = pd.dist_phase3(recv.data_ptr())
+    g2 = torch.empty(world * 512, dtype=torch.uint8)
+    dist.all_gather_into_tensor(g2, torch.frombuffer(bytearray(part2), dtype=torch.uint8))
+    proof2 = pd.prove_finish(r, s, g2.numpy().tobytes())
+    assert proof2.raw == o.proof_to_bytes(want), "fully sharded proof differs from the oracle"
     assert o.verify_proof(opk, w[1:2], H.proof_from_bytes(proof.raw))
     # every rank must have produced the identical proof
     t = torch.frombuffer(bytearray(proof.raw), dtype=torch.uint8).clone()
@@ -51,7 +66,8 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def test_two_rank_sharded_prove_gloo(emu, tmp_path):
+@pytest.mark.parametrize("world,logm", [(2, 4), (4, 6)])
+def test_sharded_prove_gloo(emu, tmp_path, world, logm):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     import socket
@@ -59,8 +75,9 @@ def test_two_rank_sharded_prove_gloo(emu, tmp_path):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script), ROOT]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script), ROOT, str(logm)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    for k in range(world):
+        assert f"rank {k} ok" in r.stdout
