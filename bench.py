@@ -104,7 +104,7 @@ def main():
     t_setup = time.time() - t_setup
 
     dev = f"cuda:{local_rank}"
-    gathered = torch.empty(world * 512, dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = torch.empty(world * 1024, dtype=torch.uint8, device=dev) if world > 1 else None
     if dist_wm:
         nbytes = prover.exchange_bytes()
         send = torch.empty(nbytes, dtype=torch.uint8, device=dev)

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libg16_amd.so")
 G16_OK, G16_ERR_INVALID, G16_ERR_DOMAIN_TOO_LARGE, G16_ERR_HIP, G16_ERR_NO_DEVICE, G16_ERR_IO, \
     G16_ERR_INTERNAL = range(7)
 G16_PROOF_BYTES = 256
-G16_PARTIAL_BYTES = 512
+G16_PARTIAL_BYTES = 1024
 G16_N_STAGES = 8
 QUERY_A, QUERY_B1, QUERY_L, QUERY_H = 0, 1, 2, 3
 

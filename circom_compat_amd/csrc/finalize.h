@@ -65,10 +65,12 @@ void fin_partial_var(ProofSums* sums, const Fr* rs_dev, hipStream_t stream);  //
 void fin_fixed_dist(const FinTables* tab, const Fr* rs_dev, FinScratch* scr, hipStream_t stream);
 void fin_final_dist(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr,
                     uint8_t* proof_dev, hipStream_t stream);
-constexpr int FIN_PARTIAL_BYTES = 512;  // A | B1 | B2 | L | H | sA | rB1, affine, storage form
-// ProofSums -> one rank's 512-byte record
+constexpr int FIN_PARTIAL_BYTES = 1024;  // A | B1 | B2 | L | H | sA | rB1 in XYZZ storage form (G1 128 B, G2 256 B)
+// ProofSums -> one rank's record (projective: no inversion before the all-gather)
 void sums_to_partial(const ProofSums* sums, uint8_t* partial_dev, hipStream_t stream);
-// world x 512-byte records -> ProofSums (local EC adds: the "all-reduce" tail)
+// A -> out[0,64), B2 -> out[128,256), affine storage form (g16_msm_g1 / g16_msm_g2)
+void sums_to_affine(const ProofSums* sums, uint8_t* out_dev, hipStream_t stream);
+// world x FIN_PARTIAL_BYTES records -> ProofSums (local EC adds: the "all-reduce" tail)
 void partials_to_sums(const uint8_t* partials_dev, int world, ProofSums* sums, hipStream_t stream);
 
 }  // namespace g16

@@ -222,15 +222,43 @@ __device__ __forceinline__ G1XYZZ29* g1_sum_slot(ProofSums* s, int b) {
   }
 }
 __device__ __forceinline__ int g1_sum_offset(int b) {  // byte offset inside a partial record
-  const int off[6] = {0, 64, 256, 320, 384, 448};
+  const int off[6] = {0, 128, 512, 640, 768, 896};
   return off[b];
 }
 
-// blocks 0..5: the six G1 sums, block 6: B2
+// A partial record carries the sums in XYZZ (projective) storage form: no field inversion sits
+// between a rank's last MSM and the all-gather.  blocks 0..5: the six G1 sums, block 6: B2;
+// lanes 0..3 convert one coordinate each.
+template <class F>
+__device__ __forceinline__ void store_xyzz(uint8_t* out, const XYZZ29<typename Lazy<F>::type>& p, int coord) {
+  F* dst = reinterpret_cast<F*>(out) + coord;
+  if (p.is_inf()) {
+    *dst = F::zero();
+    return;
+  }
+  const auto& c = coord == 0 ? p.x : (coord == 1 ? p.y : (coord == 2 ? p.zz : p.zzz));
+  *dst = c.to_mont256();
+}
+template <class F>
+__device__ __forceinline__ XYZZ29<typename Lazy<F>::type> load_xyzz(const uint8_t* in) {
+  using LF = typename Lazy<F>::type;
+  const F* src = reinterpret_cast<const F*>(in);
+  if (src[2].is_zero()) return XYZZ29<LF>::infinity();
+  return XYZZ29<LF>{LF::from_mont256(src[0]), LF::from_mont256(src[1]), LF::from_mont256(src[2]),
+                    LF::from_mont256(src[3])};
+}
+
 __global__ void __launch_bounds__(64) k_sums_to_partial(ProofSums* sums, uint8_t* out) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= 4) return;
+  if (b < 6) store_xyzz<Fq>(out + g1_sum_offset(b), *g1_sum_slot(sums, b), t);
+  else store_xyzz<Fq2>(out + 256, sums->B2, t);
+}
+
+// affine conversion of two sums for the single-MSM entry points: A -> out[0,64), B2 -> out[128,256)
+__global__ void __launch_bounds__(64) k_sums_to_affine(const ProofSums* sums, uint8_t* out) {
   if (threadIdx.x != 0) return;
-  const int b = blockIdx.x;
-  if (b < 6) *reinterpret_cast<G1Affine*>(out + g1_sum_offset(b)) = to_storage_affine<Fq>(*g1_sum_slot(sums, b));
+  if (blockIdx.x == 0) *reinterpret_cast<G1Affine*>(out) = to_storage_affine<Fq>(sums->A);
   else *reinterpret_cast<G2Affine*>(out + 128) = to_storage_affine<Fq2>(sums->B2);
 }
 
@@ -241,15 +269,11 @@ __global__ void __launch_bounds__(64) k_partials_to_sums(const uint8_t* parts, i
   if (b < 6) {
     const int off = g1_sum_offset(b);
     G1XYZZ29 acc = G1XYZZ29::infinity();
-    for (int k = 0; k < world; ++k)
-      acc.madd(affine_from_mont256<Fq>(
-          *reinterpret_cast<const G1Affine*>(parts + (size_t)k * FIN_PARTIAL_BYTES + off)));
+    for (int k = 0; k < world; ++k) acc.add(load_xyzz<Fq>(parts + (size_t)k * FIN_PARTIAL_BYTES + off));
     *g1_sum_slot(sums, b) = acc;
   } else {
     G2XYZZ29 acc = G2XYZZ29::infinity();
-    for (int k = 0; k < world; ++k)
-      acc.madd(affine_from_mont256<Fq2>(
-          *reinterpret_cast<const G2Affine*>(parts + (size_t)k * FIN_PARTIAL_BYTES + 128)));
+    for (int k = 0; k < world; ++k) acc.add(load_xyzz<Fq2>(parts + (size_t)k * FIN_PARTIAL_BYTES + 256));
     sums->B2 = acc;
   }
 }
@@ -282,6 +306,9 @@ void fin_final_dist(const KeyHeaderDev* key, const ProofSums* sums, const FinScr
 }
 void sums_to_partial(const ProofSums* sums, uint8_t* partial_dev, hipStream_t stream) {
   G16_LAUNCH(k_sums_to_partial, 7, 64, 0, stream, const_cast<ProofSums*>(sums), partial_dev);
+}
+void sums_to_affine(const ProofSums* sums, uint8_t* out_dev, hipStream_t stream) {
+  G16_LAUNCH(k_sums_to_affine, 2, 64, 0, stream, sums, out_dev);
 }
 void partials_to_sums(const uint8_t* partials_dev, int world, ProofSums* sums, hipStream_t stream) {
   G16_LAUNCH(k_partials_to_sums, 7, 64, 0, stream, partials_dev, world, sums);

@@ -29,7 +29,7 @@ constexpr int MSM_ACC_THREADS = 128;    // workgroup of the accumulation kernel
 constexpr int MSM_ACC_BLOCKS = 2048;    // persistent grid: 4 waves per SIMD on 256 CUs (G16_ACC_GRID overrides)
 constexpr int MSM_MIN_SEG = 8;          // shortest per-lane segment
 constexpr int MSM_SMALL_MULTI = 32;     // buckets with <= this many partials are summed inside the reduce
-constexpr int MSM_RED_CHUNK = 8;    // buckets per thread in the weighted bucket reduction
+constexpr int MSM_RED_CHUNK = 8;    // max buckets per thread in the weighted bucket reduction
 constexpr uint32_t MSM_IDX_BITS = 26;
 constexpr uint32_t MSM_IDX_MASK = (1u << MSM_IDX_BITS) - 1u;
 
@@ -42,6 +42,14 @@ struct MsmConfig {
   uint32_t lanes = MSM_ACC_BLOCKS * MSM_ACC_THREADS;  // segments the entry list is cut into
   uint32_t nb() const { return (uint32_t)D * B; }
 };
+
+// buckets per thread of k_bucket_reduce: as many threads as ~2 waves per SIMD, at most MSM_RED_CHUNK
+inline uint32_t msm_red_chunk(const MsmConfig& cfg) {
+  uint32_t ch = (uint32_t)(((uint64_t)cfg.D * cfg.B) / 131072u);
+  if (ch < 1) ch = 1;
+  if (ch > (uint32_t)MSM_RED_CHUNK) ch = MSM_RED_CHUNK;
+  return ch;
+}
 
 // c_override / planes_override <= 0 selects the defaults for `len` scalars.
 MsmConfig msm_make_config(size_t len, int c_override, int planes_override);

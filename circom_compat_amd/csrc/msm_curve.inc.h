@@ -162,14 +162,14 @@ __global__ void __launch_bounds__(COMB_THREADS)
 template <class F>
 __global__ void __launch_bounds__(64)
     k_bucket_reduce(const MsmAcc<F>* __restrict__ partial, const uint32_t* __restrict__ offset,
-                    uint32_t nb, uint32_t lanes, uint32_t B, uint32_t chunks_per_set,
-                    uint32_t nchunks, MsmAcc<F>* contrib) {
+                    uint32_t nb, uint32_t lanes, uint32_t B, uint32_t red_chunk,
+                    uint32_t chunks_per_set, uint32_t nchunks, MsmAcc<F>* contrib) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nchunks) return;
   const uint32_t S = msm_seg_len(offset[nb], lanes);
   const uint32_t set = q / chunks_per_set;
-  const uint32_t lo = (q % chunks_per_set) * (uint32_t)MSM_RED_CHUNK;
-  uint32_t hi = lo + MSM_RED_CHUNK;
+  const uint32_t lo = (q % chunks_per_set) * red_chunk;
+  uint32_t hi = lo + red_chunk;
   if (hi > B) hi = B;
   MsmAcc<F> run = MsmAcc<F>::infinity(), acc = MsmAcc<F>::infinity();
   for (uint32_t b = hi; b-- > lo;) {
@@ -273,11 +273,14 @@ void msm_run(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<
   G16_LAUNCH((k_combine_large<F>), 1024, COMB_THREADS, COMB_THREADS * sizeof(MsmAcc<F>), stream,
              (const uint32_t*)s.multi_l.p, (const uint32_t*)s.meta.p,
              (const uint32_t*)s.offset.p, nb, cfg.lanes, work.partial.p);
-  const uint32_t cps = ceil_div(cfg.B, MSM_RED_CHUNK);
+  // buckets per thread: the running sums are a dependent chain of EC additions (~10 us each on
+  // one lane), so small bucket sets are latency bound: keep >= ~2 waves per SIMD busy
+  const uint32_t red_chunk = msm_red_chunk(cfg);
+  const uint32_t cps = ceil_div(cfg.B, red_chunk);
   const uint32_t nchunks = cps * (uint32_t)cfg.D;
   G16_LAUNCH((k_bucket_reduce<F>), ceil_div(nchunks, 64), 64, 0, stream,
-             (const MsmAcc<F>*)work.partial.p, (const uint32_t*)s.offset.p, nb, cfg.lanes, cfg.B, cps,
-             nchunks, work.contrib.p);
+             (const MsmAcc<F>*)work.partial.p, (const uint32_t*)s.offset.p, nb, cfg.lanes, cfg.B,
+             red_chunk, cps, nchunks, work.contrib.p);
   // two-level tree: cps contributions -> nblk block sums -> 1 per set
   uint32_t nblk = ceil_div(cps, SUM_THREADS * 2);
   if (nblk > 256) nblk = 256;

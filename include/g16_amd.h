@@ -76,7 +76,8 @@ typedef struct {
 } g16_options;
 
 #define G16_PROOF_BYTES 256   /* A(64) | B(128) | C(64), affine */
-#define G16_PARTIAL_BYTES 512 /* A | B1 | B2(128) | L | H | s*A | r*B1: one rank's sums (affine) */
+#define G16_PARTIAL_BYTES 1024 /* A | B1 | B2 | L | H | s*A | r*B1: one rank's sums, XYZZ (x, y, zz, zzz;
+                                  x/zz, y/zzz affine), Montgomery; G1 128 B, G2 256 B; zz = 0: infinity */
 
 enum { G16_QUERY_A = 0, G16_QUERY_B1 = 1, G16_QUERY_L = 2, G16_QUERY_H = 3 };
 

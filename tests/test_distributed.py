@@ -35,7 +35,7 @@ WORKER = textwrap.dedent('''
     pr = cc.Prover(pk, mats, lib=lib, rank=rank, world=world)
     part = pr.prove_partial(r, s, w)
     mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
-    gathered = torch.empty(world * 512, dtype=torch.uint8)
+    gathered = torch.empty(world * 1024, dtype=torch.uint8)
     dist.all_gather_into_tensor(gathered, mine)
     proof = pr.prove_finish(r, s, gathered.numpy().tobytes())
     want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2, len(cons), w)
@@ -51,7 +51,7 @@ WORKER = textwrap.dedent('''
     pd.dist_phase2(recv.data_ptr(), send.data_ptr())
     dist.all_to_all_single(recv, send)
     part2 = pd.dist_phase3(recv.data_ptr())
-    g2 = torch.empty(world * 512, dtype=torch.uint8)
+    g2 = torch.empty(world * 1024, dtype=torch.uint8)
     dist.all_gather_into_tensor(g2, torch.frombuffer(bytearray(part2), dtype=torch.uint8))
     proof2 = pd.prove_finish(r, s, g2.numpy().tobytes())
     assert proof2.raw == o.proof_to_bytes(want), "fully sharded proof differs from the oracle"
