@@ -262,19 +262,43 @@ __global__ void __launch_bounds__(64) k_sums_to_affine(const ProofSums* sums, ui
   else *reinterpret_cast<G2Affine*>(out + 128) = to_storage_affine<Fq2>(sums->B2);
 }
 
+// one block per sum; lane k converts rank k's record, then a log2(world)-deep tree (ranks beyond
+// 64 are folded in by strided lanes first)
 __global__ void __launch_bounds__(64) k_partials_to_sums(const uint8_t* parts, int world,
                                                          ProofSums* sums) {
-  if (threadIdx.x != 0) return;
-  const int b = blockIdx.x;
+  G16_DYN_SMEM(smem_raw);
+  const int b = blockIdx.x, t = threadIdx.x;
   if (b < 6) {
+    G1XYZZ29* sh = reinterpret_cast<G1XYZZ29*>(smem_raw);
     const int off = g1_sum_offset(b);
     G1XYZZ29 acc = G1XYZZ29::infinity();
-    for (int k = 0; k < world; ++k) acc.add(load_xyzz<Fq>(parts + (size_t)k * FIN_PARTIAL_BYTES + off));
-    *g1_sum_slot(sums, b) = acc;
+    for (int k = t; k < world; k += 64) acc.add(load_xyzz<Fq>(parts + (size_t)k * FIN_PARTIAL_BYTES + off));
+    sh[t] = acc;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+      if (t < o && t + o < world) {
+        G1XYZZ29 a = sh[t];
+        a.add(sh[t + o]);
+        sh[t] = a;
+      }
+      __syncthreads();
+    }
+    if (t == 0) *g1_sum_slot(sums, b) = sh[0];
   } else {
+    G2XYZZ29* sh = reinterpret_cast<G2XYZZ29*>(smem_raw);
     G2XYZZ29 acc = G2XYZZ29::infinity();
-    for (int k = 0; k < world; ++k) acc.add(load_xyzz<Fq2>(parts + (size_t)k * FIN_PARTIAL_BYTES + 256));
-    sums->B2 = acc;
+    for (int k = t; k < world; k += 64) acc.add(load_xyzz<Fq2>(parts + (size_t)k * FIN_PARTIAL_BYTES + 256));
+    sh[t] = acc;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+      if (t < o && t + o < world) {
+        G2XYZZ29 a = sh[t];
+        a.add(sh[t + o]);
+        sh[t] = a;
+      }
+      __syncthreads();
+    }
+    if (t == 0) sums->B2 = sh[0];
   }
 }
 
@@ -311,7 +335,7 @@ void sums_to_affine(const ProofSums* sums, uint8_t* out_dev, hipStream_t stream)
   G16_LAUNCH(k_sums_to_affine, 2, 64, 0, stream, sums, out_dev);
 }
 void partials_to_sums(const uint8_t* partials_dev, int world, ProofSums* sums, hipStream_t stream) {
-  G16_LAUNCH(k_partials_to_sums, 7, 64, 0, stream, partials_dev, world, sums);
+  G16_LAUNCH(k_partials_to_sums, 7, 64, 64 * sizeof(G2XYZZ29), stream, partials_dev, world, sums);
 }
 
 }  // namespace g16

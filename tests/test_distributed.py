@@ -62,7 +62,8 @@ WORKER = textwrap.dedent('''
     dist.broadcast(ref, src=0)
     assert torch.equal(t, ref)
     dist.destroy_process_group()
-    print("rank", rank, "ok")
+    sys.stdout.write(f"rank {rank} ok" + chr(10))    # one write(): ranks share the pipe
+    sys.stdout.flush()
 ''')
 
 
