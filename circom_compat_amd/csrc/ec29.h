@@ -109,6 +109,29 @@ struct XYZZ29 {
     x = X3;
     y = Y3;
   }
+  // Branch-free core of madd for software-pipelined callers (two independent additions per lane
+  // in ONE basic block so the scheduler can interleave their dependent multiply chains):
+  // returns acc + p by the general formula and reports through *special when the x-coordinates
+  // may coincide (~2^-23 of calls: the caller then redoes this addition with madd()).  The
+  // infinity cases are resolved by selects, not branches.
+  static G16_HD XYZZ29 madd_select(const XYZZ29& acc, const Aff29<LF>& p, bool* special) {
+    const bool acc_inf = acc.is_inf();
+    // an infinite accumulator has all-zero coordinates: give the formulas something harmless
+    LF U2 = p.x * acc.zz;
+    LF S2 = p.y * acc.zzz;
+    LF Pp = U2 - acc.x;
+    LF R = S2 - acc.y;
+    *special = !acc_inf && !p.inf && Pp.maybe_zero_mod_p();
+    LF PP = Pp.sqr();
+    LF PPP = Pp * PP;
+    LF Q = acc.x * PP;
+    LF X3 = (R.sqr() - PPP - Q.dbl()).carry();
+    LF Y3 = LF::mul_sub(R, Q - X3, acc.y, PPP);
+    XYZZ29 r{X3, Y3, acc.zz * PP, acc.zzz * PPP};
+    if (acc_inf) r = XYZZ29{p.x, p.y, LF::one(), LF::one()};
+    if (p.inf) r = acc;
+    return r;
+  }
   // add-2008-s: this += q.  12M + 2S
   G16_HD void add(const XYZZ29& q) {
     if (q.is_inf()) return;

@@ -52,55 +52,124 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offse
   return lo;
 }
 
+// per-way state of the accumulation kernel (plain struct of scalars + registers: no arrays, no
+// address-taken locals, so everything stays in VGPRs)
+template <class F>
+struct AccWay {
+  using LF = typename Lazy<F>::type;
+  uint32_t seg, pos, end, g, bend, en_next, en_next2;
+  bool live;
+  XYZZ29<LF> acc;
+  Affine<F> raw_next;
+};
+
+template <class F>
+__device__ __forceinline__ void acc_fetch(const Affine<F>* __restrict__ pts, uint32_t npts,
+                                          uint32_t idx_min, uint32_t en, Affine<F>& raw) {
+  const uint32_t idx = en & MSM_IDX_MASK;
+  if (idx >= idx_min) {
+    const uint32_t plane = (en >> MSM_IDX_BITS) & 31u;
+    raw = pts[(size_t)plane * npts + (idx - idx_min)];
+  } else {
+    raw = Affine<F>::infinity();  // entry below this query's range (public inputs of L)
+  }
+}
+
+template <class F>
+__device__ __forceinline__ void acc_way_init(AccWay<F>& w, uint32_t seg, uint32_t S, uint32_t M,
+                                             const Affine<F>* __restrict__ pts, uint32_t npts,
+                                             uint32_t idx_min, const uint32_t* __restrict__ entries,
+                                             const uint32_t* __restrict__ offset, uint32_t nb) {
+  w.seg = seg;
+  w.pos = seg * S;
+  w.live = w.pos < M;
+  w.end = w.live ? (w.pos + S < M ? w.pos + S : M) : w.pos;
+  w.acc = XYZZ29<typename Lazy<F>::type>::infinity();
+  w.raw_next = Affine<F>::infinity();
+  w.g = 0;
+  w.bend = 0;
+  w.en_next = w.en_next2 = 0;
+  if (w.live) {
+    w.g = bucket_of(offset, nb, w.pos);
+    w.bend = offset[w.g + 1];
+    w.en_next = entries[w.pos];
+    w.en_next2 = w.pos + 1 < w.end ? entries[w.pos + 1] : 0u;
+    acc_fetch<F>(pts, npts, idx_min, w.en_next, w.raw_next);
+  }
+}
+
+// bucket-boundary bookkeeping + consume the prefetched point + issue the next fetches
+template <class F>
+__device__ __forceinline__ Aff29<typename Lazy<F>::type> acc_way_prepare(
+    AccWay<F>& w, bool* step, const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min,
+    const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset,
+    MsmAcc<F>* __restrict__ partial) {
+  using LF = typename Lazy<F>::type;
+  *step = w.live && w.pos < w.end;
+  if (*step && w.pos == w.bend) {  // crossed into the next non-empty bucket: emit, restart
+    partial[w.g + w.seg] = w.acc;
+    w.acc = XYZZ29<LF>::infinity();
+    do {
+      ++w.g;
+      w.bend = offset[w.g + 1];
+    } while (w.bend == w.pos);
+  }
+  const uint32_t en = w.en_next;
+  Aff29<LF> p = load_packed_affine<F>(w.raw_next);
+  if (en >> 31) p.y = p.y.neg().carry();
+  if (!*step) p.inf = true;
+  w.en_next = w.en_next2;
+  if (*step && w.pos + 2 < w.end) w.en_next2 = entries[w.pos + 2];
+  if (*step && w.pos + 1 < w.end) acc_fetch<F>(pts, npts, idx_min, w.en_next, w.raw_next);
+  return p;
+}
+
+template <class F>
+__device__ __forceinline__ void acc_way_commit(AccWay<F>& w, bool step,
+                                               const XYZZ29<typename Lazy<F>::type>& res, bool special,
+                                               const Aff29<typename Lazy<F>::type>& p) {
+  if (special) w.acc.madd(p);  // x-coordinates may coincide: redo exactly (doubling / cancellation)
+  else w.acc = res;
+  if (step) ++w.pos;
+}
+
+// One lane = one (G2) or two (G1) equal segments of the sorted entry list.  With two ways the
+// mixed additions of both segments sit in one basic block, so the scheduler interleaves their
+// dependent multiply-add chains (a single chain cannot keep the half-rate multiplier busy: ~11
+// cycles of latency per ~4-cycle issue); a G2 addition already carries that much independent work
+// in its Fq2 products.
 template <class F>
 __global__ void __launch_bounds__(ACC_THREADS)
     k_bucket_accumulate(const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min,
                         const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset,
                         uint32_t nb, uint32_t lanes, MsmAcc<F>* __restrict__ partial) {
   using LF = typename Lazy<F>::type;
+  // measured on MI355X: two ways need ~450 VGPRs (1 wave per SIMD) and lose to one way at 3 waves
+  // per SIMD (21.4 vs 17.5 ms for the four G1 MSMs of a 2^22 proof); capped at 256 VGPRs they spill
+  constexpr bool TWO = false;
   const uint32_t M = offset[nb];
   const uint32_t S = msm_seg_len(M, lanes);
-  for (uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x; lane < lanes;
-       lane += gridDim.x * blockDim.x) {
-    uint32_t pos = lane * S;
-    if (pos >= M) break;
-    const uint32_t end = pos + S < M ? pos + S : M;
-    uint32_t g = bucket_of(offset, nb, pos);
-    uint32_t bend = offset[g + 1];
-    XYZZ29<LF> acc = XYZZ29<LF>::infinity();
-    // software pipeline: entries are read two iterations ahead, points one iteration ahead, so
-    // the random 64/128-byte gather of entry j+1 is in flight during the ~1600 multiply-adds of j
-    auto fetch = [&](uint32_t en, Affine<F>& raw) {
-      const uint32_t idx = en & MSM_IDX_MASK;
-      if (idx >= idx_min) {
-        const uint32_t plane = (en >> MSM_IDX_BITS) & 31u;
-        raw = pts[(size_t)plane * npts + (idx - idx_min)];
-      } else {
-        raw = Affine<F>::infinity();  // entry below this query's range (public inputs of L)
-      }
-    };
-    uint32_t en_next = entries[pos];
-    uint32_t en_next2 = pos + 1 < end ? entries[pos + 1] : 0u;
-    Affine<F> raw_next = Affine<F>::infinity();
-    fetch(en_next, raw_next);
-    for (; pos < end; ++pos) {
-      if (pos == bend) {  // crossed into the next non-empty bucket: emit, restart
-        partial[g + lane] = acc;
-        acc = XYZZ29<LF>::infinity();
-        do {
-          ++g;
-          bend = offset[g + 1];
-        } while (bend == pos);
-      }
-      const uint32_t en = en_next;
-      Aff29<LF> p = load_packed_affine<F>(raw_next);
-      if (en >> 31) p.y = p.y.neg().carry();
-      en_next = en_next2;
-      if (pos + 2 < end) en_next2 = entries[pos + 2];
-      if (pos + 1 < end) fetch(en_next, raw_next);
-      acc.madd(p);
+  const uint32_t nthreads = gridDim.x * blockDim.x;
+  const uint32_t way_stride = TWO ? lanes / 2 : lanes;  // way 1 of thread t owns segment t + lanes/2
+  for (uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x; t0 < way_stride; t0 += nthreads) {
+    AccWay<F> w0, w1;
+    acc_way_init<F>(w0, t0, S, M, pts, npts, idx_min, entries, offset, nb);
+    if (TWO) acc_way_init<F>(w1, t0 + way_stride, S, M, pts, npts, idx_min, entries, offset, nb);
+    if (!w0.live) break;  // segments are handed out in order: nothing left for later threads either
+    for (uint32_t it = 0; it < S; ++it) {
+      bool step0, step1 = false, sp0, sp1 = false;
+      Aff29<LF> p0 = acc_way_prepare<F>(w0, &step0, pts, npts, idx_min, entries, offset, partial);
+      Aff29<LF> p1;
+      if (TWO) p1 = acc_way_prepare<F>(w1, &step1, pts, npts, idx_min, entries, offset, partial);
+      // the arithmetic of both ways in one straight-line block
+      XYZZ29<LF> r0 = XYZZ29<LF>::madd_select(w0.acc, p0, &sp0);
+      XYZZ29<LF> r1;
+      if (TWO) r1 = XYZZ29<LF>::madd_select(w1.acc, p1, &sp1);
+      acc_way_commit<F>(w0, step0, r0, sp0, p0);
+      if (TWO) acc_way_commit<F>(w1, step1, r1, sp1, p1);
     }
-    partial[g + lane] = acc;
+    partial[w0.g + w0.seg] = w0.acc;
+    if (TWO && w1.live) partial[w1.g + w1.seg] = w1.acc;
   }
 }
 
