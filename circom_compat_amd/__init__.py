@@ -36,7 +36,7 @@ from ._binding import G16Error, SerializationError, SynthesisError  # noqa: F401
 __all__ = ["read_zkey", "R1CSFile", "R1CS", "CircomCircuit", "CircomReduction", "Groth16",
            "Prover", "ProvingKey", "VerifyingKey", "ConstraintMatrices", "Proof", "G16Error",
            "SynthesisError", "SerializationError", "fr_from_ints", "fr_to_ints", "read_wtns",
-           "trapdoor_setup", "Csr"]
+           "trapdoor_setup", "Csr", "write_zkey"]
 
 FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
@@ -256,6 +256,18 @@ class R1CS:
         return ConstraintMatrices(self.num_inputs, self.num_aux, self.num_constraints, self.a, self.b)
 
 
+def write_zkey(path, pk: "ProvingKey", matrices: "ConstraintMatrices", lib: Optional[B.Library] = None):
+    """snarkjs-format .zkey for a key held in packed arrays (inverse of read_zkey; format notes:
+    reference src/zkey.rs:1-27).  Lets synthetic keys go through the loader path."""
+    lib = lib or B.load()
+    kd = pk.to_c()
+    a, b = matrices.a.to_c(), matrices.b.to_c()
+    ic = np.ascontiguousarray(pk.vk.gamma_abc_g1, dtype=np.uint8)
+    g2 = np.frombuffer(bytes(pk.vk.gamma_g2), dtype=np.uint8)
+    lib.check(lib.g16_zkey_write(os.fsencode(path), C.byref(kd), _np_ptr(ic), _np_ptr(g2), C.byref(a),
+                                 C.byref(b), matrices.num_constraints), loader=True)
+
+
 def read_wtns(src, lib: Optional[B.Library] = None) -> np.ndarray:
     """snarkjs .wtns -> (n, 4) uint64 Montgomery witness."""
     lib = lib or B.load()
@@ -279,6 +291,21 @@ class CircomCircuit:
     def __init__(self, r1cs: R1CS, witness=None):
         self.r1cs = r1cs
         self.witness = witness
+
+    def first_unsatisfied(self, lib: Optional[B.Library] = None, device=0) -> int:
+        """row index of the first constraint (A.w)(B.w) != C.w, or -1: the debug-build check of
+        CircomBuilder::build (reference src/circom/builder.rs:101-114) as a GPU kernel"""
+        lib = lib or B.load()
+        w = _as_fr(self.witness, lib)
+        a, b, c = self.r1cs.a.to_c(), self.r1cs.b.to_c(), self.r1cs.c.to_c()
+        out = C.c_int64(-2)
+        lib.check(lib.g16_check_satisfied(device, C.byref(a), C.byref(b), C.byref(c),
+                                          self.r1cs.num_constraints, _np_ptr(w), w.shape[0],
+                                          C.byref(out)))
+        return int(out.value)
+
+    def is_satisfied(self, lib: Optional[B.Library] = None) -> bool:
+        return self.first_unsatisfied(lib) < 0
 
     def get_public_inputs(self):
         if self.witness is None:

@@ -650,6 +650,30 @@ g16_status g16_ctx_info(const g16_ctx* c, uint32_t out[16]) {
 
 void* g16_witness_buffer(g16_ctx* c) { return c ? (void*)c->w_dev.p : nullptr; }
 
+g16_status g16_check_satisfied(int device, const g16_csr* a, const g16_csr* b, const g16_csr* c_,
+                               uint32_t num_constraints, const uint64_t* w, size_t n_vars,
+                               int64_t* first_unsatisfied) {
+  if (!a || !b || !c_ || !w || !first_unsatisfied) return fail(nullptr, G16_ERR_INVALID, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, G16_ERR_NO_DEVICE, "no HIP device visible");
+  for (const g16_csr* m : {a, b, c_})
+    for (uint64_t j = 0; j < m->nnz; ++j)
+      if (m->col[j] >= n_vars) return fail(nullptr, G16_ERR_INVALID, "wire index beyond the witness");
+  try {
+    G16_HIP(hipSetDevice(device));
+    CsrHost A{a->row_ptr, a->col, (const Fr*)a->coeff, (size_t)a->nnz};
+    CsrHost B{b->row_ptr, b->col, (const Fr*)b->coeff, (size_t)b->nnz};
+    CsrHost Cm{c_->row_ptr, c_->col, (const Fr*)c_->coeff, (size_t)c_->nnz};
+    *first_unsatisfied = check_satisfied(A, B, Cm, num_constraints, (const Fr*)w, n_vars);
+    return G16_OK;
+  } catch (const HipError& e) {
+    return fail(nullptr, G16_ERR_HIP, e.what());
+  } catch (const std::exception& e) {
+    return fail(nullptr, G16_ERR_INTERNAL, e.what());
+  }
+}
+
 g16_status g16_debug_ntt(int device, uint64_t* data, int log_n, int inverse, int algo) {
   if (!data || log_n < 0) return fail(nullptr, G16_ERR_INVALID, "bad argument");
   int ndev = 0;

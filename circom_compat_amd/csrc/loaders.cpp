@@ -534,6 +534,91 @@ g16_status g16_wtns_read(const char* path, uint64_t** out, uint32_t* n) {
 
 void g16_free(void* p) { free(p); }
 
+/* snarkjs .zkey writer (format: SURVEY.md Appendix A.2 = what read_zkey parses, reference
+ * src/zkey.rs:1-27,73-133,151-196,288-368).  Coefs(4) values are stored as v * R^2 (the reader
+ * divides by R^2, zkey.rs:320-325), points in the Montgomery encoding the key arrays already have;
+ * the n_public + 1 rows snarkjs appends (row m+i: A coefficient 1 on signal i) are written too.    */
+g16_status g16_zkey_write(const char* path, const g16_key_desc* key, const uint8_t* ic,
+                          const uint8_t gamma_g2[128], const g16_csr* a, const g16_csr* b,
+                          uint32_t num_constraints) {
+  if (!path || !key || !ic || !gamma_g2 || !a || !b) return fail(G16_ERR_INVALID, "null argument");
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(G16_ERR_IO, std::string("cannot create ") + path);
+  bool ok = true;
+  auto put = [&](const void* p, size_t n) { ok = ok && (n == 0 || fwrite(p, 1, n, f) == n); };
+  auto u32 = [&](uint32_t v) { put(&v, 4); };
+  auto u64 = [&](uint64_t v) { put(&v, 8); };
+  auto sec = [&](uint32_t id, uint64_t len) {
+    u32(id);
+    u64(len);
+  };
+  const uint32_t N = key->n_vars, p = key->n_public;
+  const uint64_t ncoef = a->nnz + b->nnz + p + 1;
+  put("zkey", 4);
+  u32(1);
+  u32(10);
+  sec(1, 4);
+  u32(1);  // groth16
+  sec(2, 4 + 32 + 4 + 32 + 12 + 64 + 64 + 128 + 128 + 64 + 128);
+  u32(32);
+  put(g16::FqParams::MOD, 32);
+  u32(32);
+  put(g16::FrParams::MOD, 32);
+  u32(N);
+  u32(p);
+  u32(key->domain_size);
+  put(key->alpha_g1, 64);
+  put(key->beta_g1, 64);
+  put(key->beta_g2, 128);
+  put(gamma_g2, 128);
+  put(key->delta_g1, 64);
+  put(key->delta_g2, 128);
+  sec(3, (uint64_t)(p + 1) * 64);
+  put(ic, (size_t)(p + 1) * 64);
+  sec(4, 4 + ncoef * (12 + 32));
+  u32((uint32_t)ncoef);
+  const Fr r2 = Fr::r2();
+  auto coefs = [&](uint32_t which, const g16_csr* m) {
+    for (uint32_t row = 0; row < num_constraints; ++row)
+      for (uint32_t j = m->row_ptr[row]; j < m->row_ptr[row + 1]; ++j) {
+        u32(which);
+        u32(row);
+        u32(m->col[j]);
+        Fr v;
+        memcpy(v.v, m->coeff + (size_t)j * 4, 32);
+        // v holds the limbs of coeff * R; the Montgomery product with R^2 is (coeff R)(R^2)/R =
+        // coeff * R^2 mod r: exactly the integer snarkjs stores
+        const Fr vr = v * r2;
+        put(vr.v, 32);
+      }
+  };
+  coefs(0, a);
+  coefs(1, b);
+  for (uint32_t i = 0; i <= p; ++i) {
+    u32(0);
+    u32(num_constraints + i);
+    u32(i);
+    const Fr one_r2 = Fr::one() * r2;  // 1 * R^2
+    put(one_r2.v, 32);
+  }
+  sec(5, (uint64_t)N * 64);
+  put(key->a_query, (size_t)N * 64);
+  sec(6, (uint64_t)N * 64);
+  put(key->b_g1_query, (size_t)N * 64);
+  sec(7, (uint64_t)N * 128);
+  put(key->b_g2_query, (size_t)N * 128);
+  sec(8, (uint64_t)(N - p - 1) * 64);
+  put(key->l_query, (size_t)(N - p - 1) * 64);
+  sec(9, (uint64_t)key->domain_size * 64);
+  put(key->h_query, (size_t)key->domain_size * 64);
+  sec(10, 4 + 64);
+  u32(0);
+  uint8_t zeros[64] = {0};
+  put(zeros, 64);
+  ok = (fclose(f) == 0) && ok;
+  return ok ? G16_OK : fail(G16_ERR_IO, "short write");
+}
+
 g16_status g16_fr_from_canonical(const uint8_t* in, uint64_t* out, size_t n) {
   if (!in || !out) return fail(G16_ERR_INVALID, "null argument");
   for (size_t i = 0; i < n; ++i) {

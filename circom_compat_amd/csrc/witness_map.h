@@ -36,4 +36,8 @@ struct WitnessMap {
   void run(const Fr* w_dev, U256* h_canon, Fr* h_mont, hipStream_t stream);
 };
 
+// first row i with (A_i.w)(B_i.w) != C_i.w, or -1 (host pointers; uploads, checks, frees)
+long long check_satisfied(const CsrHost& A, const CsrHost& B, const CsrHost& C, uint32_t m,
+                          const Fr* w_host, size_t n_vars);
+
 }  // namespace g16

@@ -72,7 +72,53 @@ __global__ void __launch_bounds__(256) k_mul_sub(const int32_t* abc, U256* h_can
   }
 }
 
+// (A_i . w)(B_i . w) == C_i . w for every row; records the smallest failing row
+__global__ void __launch_bounds__(256) k_check_rows(CsrDev A, CsrDev B, CsrDev C, const Fr* w,
+                                                    uint32_t m, unsigned long long* first_bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const Fr a = row_dot(A.rowptr, A.col, A.val, w, i);
+  const Fr b = row_dot(B.rowptr, B.col, B.val, w, i);
+  const Fr c = row_dot(C.rowptr, C.col, C.val, w, i);
+  if (a * b != c) atomicMin(first_bad, (unsigned long long)i);
+}
+
 }  // namespace
+
+// The satisfiability check CircomBuilder::build runs in debug builds (reference
+// src/circom/builder.rs:101-114, ConstraintSystem::is_satisfied in tests at circuit.rs:92-107)
+// as one kernel.  Returns the first unsatisfied row, or -1.
+long long check_satisfied(const CsrHost& A, const CsrHost& B, const CsrHost& C, uint32_t m,
+                          const Fr* w_host, size_t n_vars) {
+  CsrStore d[3];
+  const CsrHost* hs[3] = {&A, &B, &C};
+  for (int k = 0; k < 3; ++k) {
+    d[k].rowptr.alloc((size_t)m + 1);
+    d[k].col.alloc(hs[k]->nnz ? hs[k]->nnz : 1);
+    d[k].val.alloc(hs[k]->nnz ? hs[k]->nnz : 1);
+    G16_HIP(hipMemcpy(d[k].rowptr.p, hs[k]->rowptr, ((size_t)m + 1) * 4, hipMemcpyHostToDevice));
+    if (hs[k]->nnz) {
+      G16_HIP(hipMemcpy(d[k].col.p, hs[k]->col, hs[k]->nnz * 4, hipMemcpyHostToDevice));
+      G16_HIP(hipMemcpy(d[k].val.p, hs[k]->val, hs[k]->nnz * sizeof(Fr), hipMemcpyHostToDevice));
+    }
+  }
+  DevBuf<Fr> w;
+  w.alloc(n_vars ? n_vars : 1);
+  G16_HIP(hipMemcpy(w.p, w_host, n_vars * sizeof(Fr), hipMemcpyHostToDevice));
+  DevBuf<unsigned long long> bad;
+  bad.alloc(1);
+  const unsigned long long none = ~0ull;
+  G16_HIP(hipMemcpy(bad.p, &none, 8, hipMemcpyHostToDevice));
+  if (m) {
+    CsrDev a{d[0].rowptr.p, d[0].col.p, d[0].val.p}, b{d[1].rowptr.p, d[1].col.p, d[1].val.p},
+        c{d[2].rowptr.p, d[2].col.p, d[2].val.p};
+    G16_LAUNCH(k_check_rows, ceil_div(m, 256), 256, 0, nullptr, a, b, c, (const Fr*)w.p, m, bad.p);
+  }
+  unsigned long long out = none;
+  G16_HIP(hipDeviceSynchronize());
+  G16_HIP(hipMemcpy(&out, bad.p, 8, hipMemcpyDeviceToHost));
+  return out == none ? -1 : (long long)out;
+}
 
 void WitnessMap::init(const CsrHost& A, const CsrHost& B, uint32_t m_, uint32_t num_inputs_) {
   m = m_;

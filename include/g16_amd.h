@@ -153,6 +153,14 @@ g16_status g16_ctx_info(const g16_ctx* ctx, uint32_t out[16]);
 /* device pointer of the ctx's witness staging buffer (n_vars x 32 bytes) for g16_prove_dev        */
 void* g16_witness_buffer(g16_ctx* ctx);
 
+/* Constraint satisfaction of a witness: (A_i . w)(B_i . w) == C_i . w for every row, the check
+ * CircomBuilder::build performs in debug builds (reference src/circom/builder.rs:101-114; the
+ * reference's unit test at src/circom/circuit.rs:92-107 asserts cs.is_satisfied()).  a, b, c: the
+ * R1CS rows as CSR (g16_r1cs_matrices); *first_unsatisfied = row index, or -1 when satisfied.     */
+g16_status g16_check_satisfied(int device, const g16_csr* a, const g16_csr* b, const g16_csr* c,
+                               uint32_t num_constraints, const uint64_t* w, size_t n_vars,
+                               int64_t* first_unsatisfied);
+
 /* ---- debug / parity entry points (tests) ----------------------------------------------------- */
 /* In-place size-2^log_n NTT of host data, natural order in and out (ark-poly fft_in_place /
  * ifft_in_place semantics).  algo 0: DIF kernels + bit-reversal; algo 1: bit-reversal + DIT

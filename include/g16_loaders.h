@@ -45,6 +45,15 @@ g16_status g16_zkey_key(const g16_zkey* z, g16_key_desc* out);
 const uint8_t* g16_zkey_ic(const g16_zkey* z, uint32_t* count);
 g16_status g16_zkey_matrices(g16_zkey* z, g16_matrices* out);
 
+/* snarkjs-format .zkey WRITER: the inverse of g16_zkey_open for a key held in packed arrays (e.g.
+ * one minted by g16_setup_create) -- lets synthetic circuits go through the same file format and
+ * loader path as circom/snarkjs artefacts (reference format notes: src/zkey.rs:1-27).  ic:
+ * (n_public + 1) x 64 bytes; a, b: ConstraintMatrices rows WITHOUT the n_public + 1 rows snarkjs
+ * appends (they are generated).                                                                    */
+g16_status g16_zkey_write(const char* path, const g16_key_desc* key, const uint8_t* ic,
+                          const uint8_t gamma_g2[128], const g16_csr* a, const g16_csr* b,
+                          uint32_t num_constraints);
+
 /* ---------------------------------------------------------------- .r1cs ---------------------- */
 typedef struct g16_r1cs g16_r1cs;
 

@@ -71,6 +71,12 @@ static inline T atomicAdd(T* p, T v) {
   return o;
 }
 template <class T>
+static inline T atomicMin(T* p, T v) {
+  T o = *p;
+  if (v < o) *p = v;
+  return o;
+}
+template <class T>
 static inline T atomicMax(T* p, T v) {
   T o = *p;
   if (v > o) *p = v;

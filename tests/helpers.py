@@ -82,3 +82,48 @@ def squaring_chain(k_or_m, x0=3, m=None):
     for j, x in enumerate(xs):
         w[wire(j)] = x
     return cons, w, n_vars, 1
+
+
+def dense_skewed_circuit(m, seed=0, n_inputs=8, long_rows=()):
+    """SURVEY 8(d) config-5 substitute: seeded R1CS with 3-term A rows / 2-term B rows and small +-
+    coefficients (the shape of circuit2.r1cs: 2.95 / 1.96 nnz per row), a few very long rows, and
+    a skewed witness (>= 50 % of the scalars in {0, 1}, as bit-decomposition circuits have),
+    satisfiable by construction: row i defines a fresh wire out_i = (A_i.w)(B_i.w).
+    Returns (constraints [(A, B, C)] with [(wire, coeff)] lists, witness ints, n_vars, n_public)."""
+    import random
+    rng = random.Random(seed)
+    R = o.R_MOD
+    w = [1, 0]                                    # wire 0 = 1, wire 1 = public output (set at the end)
+    w += [rng.randrange(2) for _ in range(n_inputs)]
+    bits = list(range(2, 2 + n_inputs))
+    cons = []
+    coeffs = [1, R - 1, 2, R - 2, 3]
+
+    def lc(terms):
+        return sum(c * w[i] for i, c in terms) % R
+
+    def distinct(k, pool):
+        return rng.sample(pool, k) if len(pool) >= k else [rng.choice(pool) for _ in range(k)]
+
+    for i in range(m):
+        hi = len(w)
+        if i in long_rows:
+            A = [(wi, rng.choice(coeffs)) for wi in distinct(min(65, hi - 2), list(range(2, hi)))]
+            B = [(wi, rng.choice(coeffs)) for wi in distinct(min(64, hi - 2), list(range(2, hi)))]
+        elif rng.random() < 0.55:
+            xi, xj, xk = distinct(3, bits)
+            A = [(xi, 1), (xj, 1), (xk, R - 1)]                # in {-1, 0, 1, 2}
+            B = [(rng.choice(bits), 1)]
+            if rng.random() < 0.5:                             # 2-term B: bit * (1 - bit2) style
+                B = [(0, 1), (rng.choice(bits), R - 1)]
+        else:
+            A = [(wi, rng.choice(coeffs)) for wi in distinct(3, list(range(2, hi)))]
+            B = [(wi, rng.choice(coeffs)) for wi in distinct(2, list(range(2, hi)))]
+        val = lc(A) * lc(B) % R
+        w.append(val)
+        if val in (0, 1):
+            bits.append(len(w) - 1)
+        cons.append((A, B, [(len(w) - 1, 1)]))
+    w[1] = w[-1]                                   # public output: the last defined wire
+    cons.append(([(len(w) - 1, 1)], [(0, 1)], [(1, 1)]))
+    return cons, w, len(w), 1

@@ -174,3 +174,31 @@ def test_fully_sharded_prover_emulated_ranks_one_gpu(gpulib, logm, world):
               gamma_g2=o.g2_from_bytes(bytes(pk.vk.gamma_g2)), delta_g2=o.g2_from_bytes(bytes(pk.vk.delta_g2)),
               ic=[o.g1_from_bytes(bytes(x)) for x in pk.vk.gamma_abc_g1])
     assert o.verify_proof(vk, [w_ints[1]], H.proof_from_bytes(proof.raw))
+
+
+@pytest.mark.gpu
+def test_dense_skewed_circuit_2p14_vs_cpu_restatement(gpulib, tmp_path):
+    """config-5 substitute at 2^14 rows: uneven rows, hot buckets from a 0/1-heavy witness; key minted
+    on the GPU, written and re-read through the zkey path; GPU proof == C restatement's proof."""
+    import circom_compat_amd as cc
+    import cpu_ref
+    cons, w, n_vars, n_pub = H.dense_skewed_circuit((1 << 14) - 3, seed=14, n_inputs=64, long_rows=(100, 9000))
+    frac01 = sum(1 for x in w if x in (0, 1)) / len(w)
+    assert frac01 >= 0.5
+    rows = lambda k: [[(c, wdx) for wdx, c in con[k]] for con in cons]
+    a, b, c = (cc.Csr.from_rows(rows(k)) for k in range(3))
+    r1cs_like = type("R", (), dict(a=a, b=b, c=c, num_constraints=len(cons), wire_mapping=None, num_inputs=2))
+    assert cc.CircomCircuit(r1cs_like, w).first_unsatisfied() == -1
+    rng = random.Random(14)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    pk = cc.trapdoor_setup(a, b, c, n_vars, n_pub, tox)
+    mats = cc.ConstraintMatrices(2, n_vars - 1, len(cons), a, b)
+    path = str(tmp_path / "dense14.zkey")
+    cc.write_zkey(path, pk, mats)
+    pk2, mats2 = cc.read_zkey(path)
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    rs = cc.fr_from_ints([r, s])
+    wm = cc.fr_from_ints(w)
+    proof = cc.Prover(pk2, mats2).prove(rs[0], rs[1], wm)
+    want = cpu_ref.prove(pk2, mats2, rs[0:1].copy(), rs[1:2].copy(), wm)
+    assert proof.raw == want

@@ -223,3 +223,57 @@ def test_trapdoor_setup_vs_oracle(lib):
     mats = cc.ConstraintMatrices(2, n_vars - 1, len(cons), a, b)
     proof = cc.Prover(pk, mats, lib=lib).prove(123, 456, w)
     assert o.verify_proof(opk, w[1:2], H.proof_from_bytes(proof.raw))
+
+
+def test_constraint_satisfaction_kernel(lib, golden):
+    """reference src/circom/circuit.rs:92-107 (cs.is_satisfied()) and the debug-build check of
+    CircomBuilder::build (src/circom/builder.rs:101-114), on the reference's own fixtures"""
+    import circom_compat_amd as cc
+    import json
+    r1 = cc.R1CS.from_file(os.path.join(golden, "mycircuit.r1cs"), lib)
+    assert cc.CircomCircuit(r1, [1, 33, 3, 11]).first_unsatisfied(lib) == -1
+    assert cc.CircomCircuit(r1, [1, 34, 3, 11]).first_unsatisfied(lib) == 0
+    r2 = cc.R1CS.from_file(os.path.join(golden, "circuit2.r1cs"), lib)
+    w2 = [int(x) for x in json.load(open(os.path.join(golden, "safe-circuit-witness.json")))]
+    c2 = cc.CircomCircuit(r2, w2)
+    assert c2.is_satisfied(lib)
+    w_bad = list(w2)
+    w_bad[70] = (w_bad[70] + 1) % o.R_MOD
+    bad = cc.CircomCircuit(r2, w_bad).first_unsatisfied(lib)
+    # the oracle names the same first failing row
+    cons = o.read_r1cs(open(os.path.join(golden, "circuit2.r1cs"), "rb").read())["constraints"]
+    lc = lambda terms: sum(c * w_bad[j] for j, c in terms) % o.R_MOD
+    want = next(i for i, (A, B, Cc) in enumerate(cons) if lc(A) * lc(B) % o.R_MOD != lc(Cc))
+    assert bad == want
+
+
+def test_dense_skewed_circuit_through_zkey_writer_and_loader(lib, tmp_path):
+    """SURVEY 8(d) config 5 (substitute family): uneven rows (3/2-term and two 65/64-term rows), a
+    witness with most scalars in {0,1}; the key is minted on the device, written by the product's
+    zkey writer, re-read by the product's read_zkey (Coefs(4) path, src/zkey.rs:151-196), and the
+    proof must equal the oracle's byte for byte."""
+    import circom_compat_amd as cc
+    cons, w, n_vars, n_pub = H.dense_skewed_circuit(60, seed=5, long_rows=(17, 41))
+    assert sum(1 for x in w if x in (0, 1)) * 2 >= len(w) - 10
+    rows = lambda k: [[(c, wdx) for wdx, c in con[k]] for con in cons]
+    a, b, c = (cc.Csr.from_rows(rows(k), lib) for k in range(3))
+    r1cs_like = type("R", (), dict(a=a, b=b, c=c, num_constraints=len(cons), wire_mapping=None, num_inputs=2))
+    assert cc.CircomCircuit(r1cs_like, w).first_unsatisfied(lib) == -1
+    rng = random.Random(9)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    pk = cc.trapdoor_setup(a, b, c, n_vars, n_pub, tox, lib=lib)
+    mats = cc.ConstraintMatrices(2, n_vars - 1, len(cons), a, b)
+    path = str(tmp_path / "dense.zkey")
+    cc.write_zkey(path, pk, mats, lib=lib)
+    pk2, mats2 = cc.read_zkey(path, lib)
+    assert (pk2.n_vars, pk2.n_public, pk2.domain_size) == (pk.n_vars, pk.n_public, pk.domain_size)
+    assert np.array_equal(pk2.a_query, pk.a_query) and np.array_equal(pk2.h_query, pk.h_query)
+    assert mats2.num_constraints == len(cons)
+    assert np.array_equal(mats2.a.row_ptr, a.row_ptr) and np.array_equal(mats2.b.coeff, b.coeff)
+    # the oracle parses the same file and proves with it
+    opk, omats = o.read_zkey(open(path, "rb").read())
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    want = o.create_proof_with_reduction_and_matrices(opk, r, s, omats, 2, len(cons), w)
+    assert o.verify_proof(opk, w[1:2], want)
+    proof = cc.Groth16.create_proof_with_reduction_and_matrices(pk2, r, s, mats2, 2, len(cons), w, lib=lib)
+    assert proof.raw == o.proof_to_bytes(want)
