@@ -98,12 +98,15 @@ struct MsmPoints {
 
 template <class F>
 struct MsmWork {
-  DevBuf<MsmAcc<F>> partial;  // slot = bucket + lane: nb + lanes slots
-  DevBuf<MsmAcc<F>> contrib;  // one per reduction chunk
-  DevBuf<MsmAcc<F>> bsum;     // intermediate tree level
-  DevBuf<MsmAcc<F>> wsum;     // one per bucket set
+  int batch = 1;                    // MSMs whose partials can be alive at once (workspace slots)
+  uint32_t slots = 0, ncontrib = 0;  // per slot
+  int sets = 1;
+  DevBuf<MsmAcc<F>> partial;  // [batch][slots]; slot index = bucket + lane
+  DevBuf<MsmAcc<F>> contrib;  // [batch][ncontrib]: one per reduction chunk
+  DevBuf<MsmAcc<F>> bsum;     // [batch][256 * sets]: intermediate tree level
+  DevBuf<MsmAcc<F>> wsum;     // [batch][sets]: one per bucket set
   // sized for the larger of several sorts that will share this workspace
-  void init(uint32_t n_slots, uint32_t n_contrib, int max_sets);
+  void init(uint32_t n_slots, uint32_t n_contrib, int max_sets, int batch = 1);
 };
 
 // out_dev[0] = sum_i scalar_i * P_{i - idx_min} over the entries of `s` with idx >= idx_min
@@ -111,6 +114,14 @@ struct MsmWork {
 template <class F>
 void msm_run(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min, MsmWork<F>& work,
              MsmAcc<F>* out_dev, hipStream_t stream, StageTimer* tm = nullptr);
+// The two halves of msm_run, for MSMs that share a sort (A, B1, L over the witness scalars): their
+// accumulations go into different workspace slots and ONE batched reduction finishes all of them.
+template <class F>
+void msm_accumulate(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min, MsmWork<F>& work,
+                    int slot, hipStream_t stream, StageTimer* tm = nullptr);
+template <class F>
+void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, MsmAcc<F>* out_dev,
+                hipStream_t stream, StageTimer* tm = nullptr);
 
 // Fr Montgomery -> canonical (ark-ff into_bigint), n elements
 void fr_to_canonical(const Fr* in, U256* out, uint32_t n, hipStream_t stream);

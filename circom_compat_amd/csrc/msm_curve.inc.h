@@ -211,9 +211,10 @@ template <class F>
 __global__ void __launch_bounds__(COMB_THREADS)
     k_combine_large(const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
                     const uint32_t* __restrict__ offset, uint32_t nb, uint32_t lanes,
-                    MsmAcc<F>* partial) {
+                    MsmAcc<F>* partial, size_t slot_stride) {
   G16_DYN_SMEM(smem_raw);
   MsmAcc<F>* sh = reinterpret_cast<MsmAcc<F>*>(smem_raw);
+  partial += (size_t)blockIdx.y * slot_stride;  // batch of MSMs over the same sort
   const uint32_t n = meta[1];
   const uint32_t S = msm_seg_len(offset[nb], lanes);
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
@@ -232,9 +233,12 @@ template <class F>
 __global__ void __launch_bounds__(64)
     k_bucket_reduce(const MsmAcc<F>* __restrict__ partial, const uint32_t* __restrict__ offset,
                     uint32_t nb, uint32_t lanes, uint32_t B, uint32_t red_chunk,
-                    uint32_t chunks_per_set, uint32_t nchunks, MsmAcc<F>* contrib) {
+                    uint32_t chunks_per_set, uint32_t nchunks, MsmAcc<F>* contrib,
+                    size_t slot_stride) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nchunks) return;
+  partial += (size_t)blockIdx.y * slot_stride;
+  contrib += (size_t)blockIdx.y * nchunks;
   const uint32_t S = msm_seg_len(offset[nb], lanes);
   const uint32_t set = q / chunks_per_set;
   const uint32_t lo = (q % chunks_per_set) * red_chunk;
@@ -262,9 +266,12 @@ __global__ void __launch_bounds__(64)
 // tree-sum: block (set, blk) of a (sets x nblk) grid sums its slice of the `per_set` inputs of the set
 template <class F>
 __global__ void __launch_bounds__(SUM_THREADS)
-    k_set_sum(const MsmAcc<F>* __restrict__ in, uint32_t per_set, uint32_t nblk, MsmAcc<F>* out) {
+    k_set_sum(const MsmAcc<F>* __restrict__ in, uint32_t per_set, uint32_t nblk, MsmAcc<F>* out,
+              size_t in_stride, size_t out_stride) {
   G16_DYN_SMEM(smem_raw);
   MsmAcc<F>* sh = reinterpret_cast<MsmAcc<F>*>(smem_raw);
+  in += (size_t)blockIdx.y * in_stride;
+  out += (size_t)blockIdx.y * out_stride;
   const uint32_t set = blockIdx.x / nblk, blk = blockIdx.x % nblk;
   const MsmAcc<F>* c = in + (size_t)set * per_set;
   MsmAcc<F> acc = MsmAcc<F>::infinity();
@@ -276,8 +283,10 @@ __global__ void __launch_bounds__(SUM_THREADS)
 
 // total = sum_d 2^(c*d) wsum[d]   (D == 1: plain copy)
 template <class F>
-__global__ void k_horner(const MsmAcc<F>* wsum, int D, int c, MsmAcc<F>* out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void k_horner(const MsmAcc<F>* wsum, int stride, int D, int c, MsmAcc<F>* out) {
+  if (threadIdx.x != 0) return;
+  wsum += (size_t)blockIdx.x * stride;  // one block per MSM of the batch
+  out += blockIdx.x;
   MsmAcc<F> t = wsum[D - 1];
   for (int d = D - 2; d >= 0; --d) {
     for (int s = 0; s < c; ++s) t.dbl_in_place();
@@ -317,48 +326,76 @@ void MsmPoints<F>::init(const Affine<F>* host_points, uint32_t n, const MsmConfi
 }
 
 template <class F>
-void MsmWork<F>::init(uint32_t n_slots, uint32_t n_contrib, int max_sets) {
-  partial.alloc(n_slots ? n_slots : 1);
-  contrib.alloc(n_contrib ? n_contrib : 1);
-  bsum.alloc((size_t)256 * max_sets);
-  wsum.alloc(max_sets);
+void MsmWork<F>::init(uint32_t n_slots, uint32_t n_contrib, int max_sets, int batch_) {
+  slots = n_slots ? n_slots : 1;
+  ncontrib = n_contrib ? n_contrib : 1;
+  sets = max_sets;
+  batch = batch_;
+  partial.alloc((size_t)batch * slots);
+  contrib.alloc((size_t)batch * ncontrib);
+  bsum.alloc((size_t)batch * 256 * sets);
+  wsum.alloc((size_t)batch * sets);
 }
 
 template <class F>
-void msm_run(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<F>& work,
-             MsmAcc<F>* out_dev, hipStream_t stream, StageTimer* tm) {
+void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<F>& work,
+                    int slot, hipStream_t stream, StageTimer* tm) {
   const MsmConfig& cfg = s.cfg;
   const uint32_t nb = cfg.nb();
   const int acc_stage = sizeof(F) == sizeof(Fq) ? ST_MSM_ACC_G1 : ST_MSM_ACC_G2;
+  if (slot < 0 || slot >= work.batch) throw std::runtime_error("msm_accumulate: bad workspace slot");
   // persistent grid: cfg.lanes lanes, each owning an equal segment of the sorted entry list
   const uint32_t grid = cfg.lanes / ACC_THREADS;
   int id = tm ? tm->begin(acc_stage, stream) : -1;
   G16_LAUNCH((k_bucket_accumulate<F>), grid, ACC_THREADS, 0, stream, (const Affine<F>*)P.pts.p,
              P.count, idx_min, (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb,
-             cfg.lanes, work.partial.p);
+             cfg.lanes, work.partial.p + (size_t)slot * work.slots);
   if (tm) tm->end(id, stream);
+}
 
-  id = tm ? tm->begin(ST_MSM_REDUCE, stream) : -1;
-  G16_LAUNCH((k_combine_large<F>), 1024, COMB_THREADS, COMB_THREADS * sizeof(MsmAcc<F>), stream,
-             (const uint32_t*)s.multi_l.p, (const uint32_t*)s.meta.p,
-             (const uint32_t*)s.offset.p, nb, cfg.lanes, work.partial.p);
+// Bucket reduction of `nbatch` MSMs (workspace slots first_slot ...) that were accumulated over
+// the SAME sort: the reduction is a chain of dependent EC additions (~0.3-0.5 ms of latency
+// whatever the size), so MSMs sharing a sort pay it once.  out_dev: nbatch consecutive sums.
+template <class F>
+void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, MsmAcc<F>* out_dev,
+                hipStream_t stream, StageTimer* tm) {
+  const MsmConfig& cfg = s.cfg;
+  const uint32_t nb = cfg.nb();
+  if (first_slot < 0 || nbatch < 1 || first_slot + nbatch > work.batch)
+    throw std::runtime_error("msm_reduce: bad workspace slots");
+  MsmAcc<F>* partial = work.partial.p + (size_t)first_slot * work.slots;
+  int id = tm ? tm->begin(ST_MSM_REDUCE, stream) : -1;
+  G16_LAUNCH((k_combine_large<F>), dim3(1024, nbatch), COMB_THREADS, COMB_THREADS * sizeof(MsmAcc<F>),
+             stream, (const uint32_t*)s.multi_l.p, (const uint32_t*)s.meta.p,
+             (const uint32_t*)s.offset.p, nb, cfg.lanes, partial, (size_t)work.slots);
   // buckets per thread: the running sums are a dependent chain of EC additions (~10 us each on
   // one lane), so small bucket sets are latency bound: keep >= ~2 waves per SIMD busy
   const uint32_t red_chunk = msm_red_chunk(cfg);
   const uint32_t cps = ceil_div(cfg.B, red_chunk);
   const uint32_t nchunks = cps * (uint32_t)cfg.D;
-  G16_LAUNCH((k_bucket_reduce<F>), ceil_div(nchunks, 64), 64, 0, stream,
-             (const MsmAcc<F>*)work.partial.p, (const uint32_t*)s.offset.p, nb, cfg.lanes, cfg.B,
-             red_chunk, cps, nchunks, work.contrib.p);
+  if (nchunks > work.ncontrib) throw std::runtime_error("msm_reduce: contribution buffer too small");
+  G16_LAUNCH((k_bucket_reduce<F>), dim3(ceil_div(nchunks, 64), nbatch), 64, 0, stream,
+             (const MsmAcc<F>*)partial, (const uint32_t*)s.offset.p, nb, cfg.lanes, cfg.B, red_chunk,
+             cps, nchunks, work.contrib.p, (size_t)work.slots);
   // two-level tree: cps contributions -> nblk block sums -> 1 per set
   uint32_t nblk = ceil_div(cps, SUM_THREADS * 2);
   if (nblk > 256) nblk = 256;
-  G16_LAUNCH((k_set_sum<F>), (uint32_t)cfg.D * nblk, SUM_THREADS, SUM_THREADS * sizeof(MsmAcc<F>),
-             stream, (const MsmAcc<F>*)work.contrib.p, cps, nblk, work.bsum.p);
-  G16_LAUNCH((k_set_sum<F>), (uint32_t)cfg.D, SUM_THREADS, SUM_THREADS * sizeof(MsmAcc<F>), stream,
-             (const MsmAcc<F>*)work.bsum.p, nblk, 1u, work.wsum.p);
-  G16_LAUNCH((k_horner<F>), 1, 64, 0, stream, (const MsmAcc<F>*)work.wsum.p, cfg.D, cfg.c, out_dev);
+  G16_LAUNCH((k_set_sum<F>), dim3((uint32_t)cfg.D * nblk, nbatch), SUM_THREADS,
+             SUM_THREADS * sizeof(MsmAcc<F>), stream, (const MsmAcc<F>*)work.contrib.p, cps, nblk,
+             work.bsum.p, (size_t)nchunks, (size_t)256 * work.sets);
+  G16_LAUNCH((k_set_sum<F>), dim3((uint32_t)cfg.D, nbatch), SUM_THREADS,
+             SUM_THREADS * sizeof(MsmAcc<F>), stream, (const MsmAcc<F>*)work.bsum.p, nblk, 1u,
+             work.wsum.p, (size_t)256 * work.sets, (size_t)work.sets);
+  G16_LAUNCH((k_horner<F>), nbatch, 64, 0, stream, (const MsmAcc<F>*)work.wsum.p, work.sets, cfg.D,
+             cfg.c, out_dev);
   if (tm) tm->end(id, stream);
+}
+
+template <class F>
+void msm_run(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<F>& work,
+             MsmAcc<F>* out_dev, hipStream_t stream, StageTimer* tm) {
+  msm_accumulate<F>(s, P, idx_min, work, 0, stream, tm);
+  msm_reduce<F>(s, work, 0, 1, out_dev, stream, tm);
 }
 
 }  // namespace g16

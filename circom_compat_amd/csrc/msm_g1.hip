@@ -5,4 +5,8 @@ template struct MsmPoints<Fq>;
 template struct MsmWork<Fq>;
 template void msm_run<Fq>(const MsmSort&, const MsmPoints<Fq>&, uint32_t, MsmWork<Fq>&, MsmAcc<Fq>*,
                           hipStream_t, StageTimer*);
+template void msm_accumulate<Fq>(const MsmSort&, const MsmPoints<Fq>&, uint32_t, MsmWork<Fq>&, int,
+                                 hipStream_t, StageTimer*);
+template void msm_reduce<Fq>(const MsmSort&, MsmWork<Fq>&, int, int, MsmAcc<Fq>*, hipStream_t,
+                             StageTimer*);
 }  // namespace g16

@@ -5,4 +5,8 @@ template struct MsmPoints<Fq2>;
 template struct MsmWork<Fq2>;
 template void msm_run<Fq2>(const MsmSort&, const MsmPoints<Fq2>&, uint32_t, MsmWork<Fq2>&,
                            MsmAcc<Fq2>*, hipStream_t, StageTimer*);
+template void msm_accumulate<Fq2>(const MsmSort&, const MsmPoints<Fq2>&, uint32_t, MsmWork<Fq2>&, int,
+                                 hipStream_t, StageTimer*);
+template void msm_reduce<Fq2>(const MsmSort&, MsmWork<Fq2>&, int, int, MsmAcc<Fq2>*, hipStream_t,
+                             StageTimer*);
 }  // namespace g16
