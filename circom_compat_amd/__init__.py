@@ -33,7 +33,7 @@ import numpy as np
 from . import _binding as B
 from ._binding import G16Error, SerializationError, SynthesisError  # noqa: F401
 
-__all__ = ["read_zkey", "R1CSFile", "R1CS", "CircomCircuit", "CircomReduction", "Groth16",
+__all__ = ["read_zkey", "R1CSFile", "R1CS", "CircomCircuit", "CircomReduction", "LibsnarkReduction", "Groth16",
            "Prover", "ProvingKey", "VerifyingKey", "ConstraintMatrices", "Proof", "G16Error",
            "SynthesisError", "SerializationError", "fr_from_ints", "fr_to_ints", "read_wtns",
            "trapdoor_setup", "Csr", "write_zkey"]
@@ -338,7 +338,7 @@ class Prover:
 
     def __init__(self, pk: Optional[ProvingKey], matrices: ConstraintMatrices, device=0, rank=0,
                  world=1, window_bits=0, planes=0, lib: Optional[B.Library] = None,
-                 n_vars: Optional[int] = None, dist_wm=False):
+                 n_vars: Optional[int] = None, dist_wm=False, reduction: str = "circom"):
         self.lib = lib or B.load()
         self.matrices = matrices
         self.pk = pk
@@ -359,6 +359,7 @@ class Prover:
         opt.device, opt.rank, opt.world = device, rank, world
         opt.window_bits, opt.planes = window_bits, planes
         opt.dist_wm = 1 if (dist_wm and world > 1) else 0
+        opt.reduction = REDUCTIONS[reduction]
         self.dist_wm = bool(opt.dist_wm)
         self.rank, self.world = rank, world
         a, b = matrices.a.to_c(), matrices.b.to_c()
@@ -491,11 +492,16 @@ def _transpose_csr(m: Csr, n_cols: int, extra=None) -> Csr:
     return Csr(rp.astype(np.uint32), rows[order].astype(np.uint32), vals[order])
 
 
+REDUCTIONS = {"circom": 0, "libsnark": 1}
+
+
 def trapdoor_setup(a: Csr, b: Csr, c: Csr, n_vars: int, n_public: int, toxic: Sequence[int],
-                   device=0, lib: Optional[B.Library] = None) -> ProvingKey:
-    """Known-toxic-waste circom/snarkjs-style setup on the GPU (g16_setup_create): the key
-    Groth16::generate_random_parameters_with_reduction::<CircomReduction> would produce for
-    (tau, alpha, beta, gamma, delta) = toxic.  Used to mint the synthetic BASELINE keys."""
+                   device=0, lib: Optional[B.Library] = None, reduction: str = "circom") -> ProvingKey:
+    """Known-toxic-waste setup on the GPU (g16_setup_create_ex): the key
+    Groth16::generate_random_parameters_with_reduction::<QAP> would produce for
+    (tau, alpha, beta, gamma, delta) = toxic, QAP = CircomReduction ("circom", snarkjs-compatible)
+    or LibsnarkReduction ("libsnark", arkworks' default: reference tests/groth16.rs:25).
+    Used to mint the synthetic BASELINE keys."""
     lib = lib or B.load()
     m = a.num_rows
     ni = n_public + 1
@@ -506,8 +512,8 @@ def trapdoor_setup(a: Csr, b: Csr, c: Csr, n_vars: int, n_public: int, toxic: Se
     tox = fr_from_ints(list(toxic), lib)
     h = C.c_void_p()
     cat, cbt, cct = at.to_c(), bt.to_c(), ct.to_c()
-    st = lib.g16_setup_create(device, C.byref(cat), C.byref(cbt), C.byref(cct), n_vars, n_public, m,
-                              _np_ptr(tox), C.byref(h))
+    st = lib.g16_setup_create_ex(device, C.byref(cat), C.byref(cbt), C.byref(cct), n_vars, n_public, m,
+                                 _np_ptr(tox), REDUCTIONS[reduction], C.byref(h))
     if st != B.G16_OK:
         raise (SynthesisError if st == B.G16_ERR_DOMAIN_TOO_LARGE else G16Error)(st, "g16_setup_create failed")
     handle = _Handle(lib, h, lib.g16_setup_destroy)
@@ -530,20 +536,33 @@ def trapdoor_setup(a: Csr, b: Csr, c: Csr, n_vars: int, n_public: int, toxic: Se
                       view(kd.h_query, kd.domain_size, 64), keepalive=handle)
 
 
-class CircomReduction:
-    """R1CSToQAP impl used for circom/snarkjs keys (reference src/circom/qap.rs:12-106)."""
+class _Reduction:
+    """R1CSToQAP::witness_map_from_matrices on the GPU; the subclass names the QAP."""
+    NAME = "circom"
 
-    @staticmethod
-    def witness_map_from_matrices(matrices: ConstraintMatrices, num_inputs: int,
+    @classmethod
+    def witness_map_from_matrices(cls, matrices: ConstraintMatrices, num_inputs: int,
                                   num_constraints: int, full_assignment, lib=None, device=0):
         if num_inputs != matrices.num_instance_variables or num_constraints != matrices.num_constraints:
             raise G16Error(B.G16_ERR_INVALID, "num_inputs/num_constraints do not match the matrices")
-        pr = getattr(matrices, "_wm_prover", None)
+        attr = "_wm_prover_" + cls.NAME
+        pr = getattr(matrices, attr, None)
         if pr is None:
             n_vars = len(full_assignment)
-            pr = Prover(None, matrices, device=device, lib=lib, n_vars=n_vars)
-            matrices._wm_prover = pr
+            pr = Prover(None, matrices, device=device, lib=lib, n_vars=n_vars, reduction=cls.NAME)
+            setattr(matrices, attr, pr)
         return pr.witness_map(full_assignment)
+
+
+class CircomReduction(_Reduction):
+    """R1CSToQAP impl used for circom/snarkjs keys (reference src/circom/qap.rs:12-106)."""
+    NAME = "circom"
+
+
+class LibsnarkReduction(_Reduction):
+    """ark_groth16::LibsnarkReduction, the default QAP of `Groth16<Bn254>` (arkworks-generated keys,
+    reference tests/groth16.rs:9,25-35).  Returns the n coefficients of h."""
+    NAME = "libsnark"
 
 
 class Groth16:
@@ -551,9 +570,23 @@ class Groth16:
 
     @staticmethod
     def _prover(pk: ProvingKey, matrices: ConstraintMatrices, **kw) -> Prover:
+        kw.setdefault("reduction", getattr(pk, "reduction", "circom"))
         if pk._prover is None or pk._prover.matrices is not matrices:
             pk._prover = Prover(pk, matrices, **kw)
         return pk._prover
+
+    @staticmethod
+    def generate_random_parameters_with_reduction(r1cs: "R1CS", rng=None, reduction: str = "libsnark",
+                                                  device=0, lib=None) -> ProvingKey:
+        """Groth16::<Bn254, QAP>::generate_random_parameters_with_reduction(circuit, rng) (reference
+        tests/groth16.rs:25, QAP defaulting to LibsnarkReduction there): toxic waste from rng, key
+        minted on the GPU.  The key remembers its reduction; Groth16.prove uses it."""
+        rng = rng or random.SystemRandom()
+        toxic = [rng.randrange(1, FR_MODULUS) for _ in range(5)]
+        pk = trapdoor_setup(r1cs.a, r1cs.b, r1cs.c, r1cs.num_variables, r1cs.num_inputs - 1, toxic,
+                            device=device, lib=lib, reduction=reduction)
+        pk.reduction = reduction
+        return pk
 
     @staticmethod
     def create_proof_with_reduction_and_matrices(pk: ProvingKey, r, s, matrices: ConstraintMatrices,

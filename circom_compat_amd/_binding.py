@@ -56,7 +56,7 @@ class KeyDesc(C.Structure):
 class Options(C.Structure):
     _fields_ = [("device", C.c_int), ("rank", C.c_int), ("world", C.c_int),
                 ("window_bits", C.c_int), ("planes", C.c_int), ("dist_wm", C.c_int),
-                ("reserved", C.c_int * 2)]
+                ("reduction", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class ZkeyHeader(C.Structure):
@@ -88,7 +88,7 @@ ABI_SYMBOLS = [
     "g16_prove_finish", "g16_dist_exchange_bytes", "g16_prove_dist_phase1", "g16_prove_dist_phase2",
     "g16_prove_dist_phase3", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info",
     "g16_witness_buffer", "g16_debug_ntt", "g16_debug_alu_bench", "g16_check_satisfied", "g16_zkey_write",
-    "g16_setup_create", "g16_setup_destroy", "g16_setup_key",
+    "g16_setup_create", "g16_setup_create_ex", "g16_setup_destroy", "g16_setup_key",
     "g16_loader_last_error", "g16_zkey_open", "g16_zkey_open_mem", "g16_zkey_close",
     "g16_zkey_header_get", "g16_zkey_key", "g16_zkey_ic", "g16_zkey_matrices", "g16_r1cs_open",
     "g16_r1cs_open_mem", "g16_r1cs_close", "g16_r1cs_header_get", "g16_r1cs_matrices",
@@ -169,6 +169,8 @@ class Library:
             "g16_fr_to_canonical": (C.c_int, [vp, vp, C.c_size_t]),
             "g16_setup_create": (C.c_int, [C.c_int, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr),
                                            C.c_uint32, C.c_uint32, C.c_uint32, vp, C.POINTER(vp)]),
+            "g16_setup_create_ex": (C.c_int, [C.c_int, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr),
+                                           C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_int, C.POINTER(vp)]),
             "g16_setup_destroy": (None, [vp]),
             "g16_setup_key": (C.c_int, [vp, C.POINTER(KeyDesc), C.POINTER(vp), _u32p, vp]),
         }

@@ -255,12 +255,16 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     c->m = num_constraints;
     CsrHost A{a->row_ptr, a->col, (const Fr*)a->coeff, (size_t)a->nnz};
     CsrHost B{b->row_ptr, b->col, (const Fr*)b->coeff, (size_t)b->nnz};
+    if (o.reduction != G16_REDUCTION_CIRCOM && o.reduction != G16_REDUCTION_LIBSNARK)
+      throw std::runtime_error("unknown reduction");
     c->dist_wm = o.dist_wm != 0 && o.world > 1;
+    if (c->dist_wm && o.reduction != G16_REDUCTION_CIRCOM)
+      throw std::runtime_error("the distributed witness map implements CircomReduction only");
     if (c->dist_wm) {
       c->wd.init(A, B, c->m, c->num_inputs, c->rank, c->world);
       c->n = c->wd.n;
     } else {
-      c->wm.init(A, B, c->m, c->num_inputs);
+      c->wm.init(A, B, c->m, c->num_inputs, o.reduction);
       c->n = c->wm.n;
     }
     if (key->domain_size != c->n)

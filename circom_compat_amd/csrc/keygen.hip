@@ -133,7 +133,15 @@ extern "C" {
 g16_status g16_setup_create(int device, const g16_csr* at, const g16_csr* bt, const g16_csr* ct,
                             uint32_t n_vars, uint32_t n_public, uint32_t num_constraints,
                             const uint64_t* toxic, g16_setup** out) {
+  return g16_setup_create_ex(device, at, bt, ct, n_vars, n_public, num_constraints, toxic,
+                             G16_REDUCTION_CIRCOM, out);
+}
+
+g16_status g16_setup_create_ex(int device, const g16_csr* at, const g16_csr* bt, const g16_csr* ct,
+                               uint32_t n_vars, uint32_t n_public, uint32_t num_constraints,
+                               const uint64_t* toxic, int reduction, g16_setup** out) {
   if (!at || !bt || !ct || !toxic || !out) return G16_ERR_INVALID;
+  if (reduction != G16_REDUCTION_CIRCOM && reduction != G16_REDUCTION_LIBSNARK) return G16_ERR_INVALID;
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return G16_ERR_NO_DEVICE;
@@ -201,10 +209,17 @@ g16_status g16_setup_create(int device, const g16_csr* at, const g16_csr* bt, co
                  (const Fr*)(uvw.p + 2 * (size_t)N), alpha, beta, ginv, dinv, num_inputs, N, lin.p);
       G16_HIP(hipDeviceSynchronize());
     }
-    // ---- H scalars (qap.rs:90-105 with max_power = n - 1)
-    G16_LAUNCH(k_powers, ceil_div(2 * n, 256), 256, 0, s, T, dinv, tmp.p, 2 * n - 1, 2 * n);
-    ntt_dif(plan_2n, tmp.p, (size_t)2 * n, 1, true, NTT_FUSE_SCALE, s);
-    G16_LAUNCH(k_gather_odd, ceil_div(n, 256), 256, 0, s, (const Fr*)tmp.p, k + 1, hk.p, n);
+    if (reduction == G16_REDUCTION_LIBSNARK) {
+      // ---- H scalars of ark-groth16's LibsnarkReduction::h_query_scalars(n - 1, tau, Z(tau), 1/delta):
+      // Z(tau)/delta * tau^i for i < n - 1; entry n - 1 is padded with 0 (-> point at infinity)
+      const Fr zt = fr_pow_u64(tau, n) - Fr::one();
+      G16_LAUNCH(k_powers, ceil_div(n, 256), 256, 0, s, T, zt * dinv, hk.p, n - 1, n);
+    } else {
+      // ---- H scalars (qap.rs:90-105 with max_power = n - 1)
+      G16_LAUNCH(k_powers, ceil_div(2 * n, 256), 256, 0, s, T, dinv, tmp.p, 2 * n - 1, 2 * n);
+      ntt_dif(plan_2n, tmp.p, (size_t)2 * n, 1, true, NTT_FUSE_SCALE, s);
+      G16_LAUNCH(k_gather_odd, ceil_div(n, 256), 256, 0, s, (const Fr*)tmp.p, k + 1, hk.p, n);
+    }
 
     // ---- fixed-base tables
     G1Affine g1{Fq::one(), Fq::one() + Fq::one()};

@@ -31,13 +31,18 @@ struct Ntt29Plan {
   DevBuf<Fr> twlo, twhi, loc[2];
   Fr n_inv_packed;               // 1/n, packed internal
   void build(int log_n, hipStream_t stream);
+  // two-level table of scale * base^j, j < n, in the packed internal form (lo: 2^h1 entries of
+  // base^l, hi: scale * base^(h 2^h1)); the plan's own twlo / twhi are make_twist(omega_2n, 1/n)
+  void make_twist(Fr base, Fr scale, DevBuf<Fr>& lo, DevBuf<Fr>& hi) const;
   size_t n() const { return base.n; }
 };
 
 // In-place transforms of `batch` vectors; vector v occupies planes data + v * vec_stride,
 // plane k at + k * n (vec_stride >= 9 n, in int32 units).
+// twlo / twhi (optional): twist tables to use with NTT_FUSE_TWIST_SCALE instead of the plan's
+// omega_2n tables (see Ntt29Plan::make_twist)
 void ntt29_dif(const Ntt29Plan& plan, int32_t* data, size_t vec_stride, int batch, bool inverse,
-               NttFuse fuse, hipStream_t stream);
+               NttFuse fuse, hipStream_t stream, const Fr* twlo = nullptr, const Fr* twhi = nullptr);
 void ntt29_dit(const Ntt29Plan& plan, int32_t* data, size_t vec_stride, int batch, hipStream_t stream);
 
 // storage form (Montgomery R = 2^256, 32 bytes per element) <-> planes

@@ -202,7 +202,8 @@ __global__ void k_bitrev_planes(const int32_t* in, int32_t* out, int k) {
 }
 
 void run_pass(const Ntt29Plan& P, const NttPass& ps, bool dit, bool inverse, int32_t* data,
-              size_t vec_stride, int batch, int fuse, hipStream_t stream) {
+              size_t vec_stride, int batch, int fuse, hipStream_t stream, const Fr* twlo = nullptr,
+              const Fr* twhi = nullptr) {
   Ntt29Args A;
   A.data = data;
   A.vec_stride = vec_stride;
@@ -217,8 +218,8 @@ void run_pass(const Ntt29Plan& P, const NttPass& ps, bool dit, bool inverse, int
   A.tlo = P.tlo[d].p;
   A.thi = P.thi[d].p;
   A.h1 = P.base.h1;
-  A.twlo = P.twlo.p;
-  A.twhi = P.twhi.p;
+  A.twlo = twlo ? twlo : P.twlo.p;
+  A.twhi = twhi ? twhi : P.twhi.p;
   A.fuse = fuse;
   A.scale = P.n_inv_packed;
   const size_t E = (size_t)1 << (ps.b + ps.logT);
@@ -253,13 +254,38 @@ void Ntt29Plan::build(int log_n, hipStream_t stream) {
 }
 
 void ntt29_dif(const Ntt29Plan& P, int32_t* data, size_t vec_stride, int batch, bool inverse,
-               NttFuse fuse, hipStream_t stream) {
+               NttFuse fuse, hipStream_t stream, const Fr* twlo, const Fr* twhi) {
   if (P.base.k == 0) return;
   for (size_t i = 0; i < P.base.passes.size(); ++i) {
     const bool last = (i + 1 == P.base.passes.size());
     run_pass(P, P.base.passes[i], false, inverse, data, vec_stride, batch, last ? (int)fuse : 0,
-             stream);
+             stream, twlo, twhi);
   }
+}
+
+void Ntt29Plan::make_twist(Fr g, Fr scale, DevBuf<Fr>& lo, DevBuf<Fr>& hi) const {
+  const size_t nlo = (size_t)1 << base.h1, nhi = (size_t)1 << (base.k - base.h1);
+  std::vector<Fr> hlo(nlo), hhi(nhi);
+  auto pack = [](const Fr& x) {
+    Fr r;
+    Fr29::from_mont256(x).pack_internal(r.v);  // host arithmetic
+    return r;
+  };
+  Fr x = Fr::one();
+  for (size_t i = 0; i < nlo; ++i) {
+    hlo[i] = pack(x);
+    x = x * g;
+  }
+  const Fr step = x;  // g^(2^h1)
+  Fr y = scale;
+  for (size_t i = 0; i < nhi; ++i) {
+    hhi[i] = pack(y);
+    y = y * step;
+  }
+  lo.alloc(nlo);
+  hi.alloc(nhi);
+  G16_HIP(hipMemcpy(lo.p, hlo.data(), nlo * sizeof(Fr), hipMemcpyHostToDevice));
+  G16_HIP(hipMemcpy(hi.p, hhi.data(), nhi * sizeof(Fr), hipMemcpyHostToDevice));
 }
 
 void ntt29_dit(const Ntt29Plan& P, int32_t* data, size_t vec_stride, int batch, hipStream_t stream) {

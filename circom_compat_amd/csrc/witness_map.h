@@ -24,11 +24,14 @@ struct CsrStore {
 
 struct WitnessMap {
   uint32_t m = 0, num_inputs = 0, n = 0;
+  int reduction = 0;  // G16_REDUCTION_*: CircomReduction (0) or ark-groth16's LibsnarkReduction (1)
   Ntt29Plan plan;
+  DevBuf<Fr> cs_lo, cs_hi, ci_lo, ci_hi;  // libsnark: coset tables g^j / n and g^-j / n (g = 5)
+  Fr z_inv_packed;                        // libsnark: 1 / (g^n - 1), packed internal
   CsrStore dA, dB;
   DevBuf<int32_t> abc;  // a | b | c as limb planes (ntt29.h): [3][9][n] int32
 
-  void init(const CsrHost& A, const CsrHost& B, uint32_t m, uint32_t num_inputs);
+  void init(const CsrHost& A, const CsrHost& B, uint32_t m, uint32_t num_inputs, int reduction = 0);
   // w_dev: full assignment (>= max column index + 1 elements, Montgomery).
   // h_canon (optional): h as canonical integers (ark-ff into_bigint form) -- what the H-query MSM
   //                     consumes; h_mont (optional): h in the storage form (Montgomery), the value

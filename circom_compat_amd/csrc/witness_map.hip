@@ -72,6 +72,37 @@ __global__ void __launch_bounds__(256) k_mul_sub(const int32_t* abc, U256* h_can
   }
 }
 
+// LibsnarkReduction, after the coset transforms: vector 0 <- (a b - c) / Z_H(coset)
+__global__ void __launch_bounds__(256) k_libsnark_quotient(int32_t* abc, Fr z_inv, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t vs = (size_t)NTT29_LIMBS * n;
+  const Fr29 one = Fr29::one();
+  const Fr29 a = load_planes(abc, n, i) * one;
+  const Fr29 b = load_planes(abc + vs, n, i);
+  const Fr29 c = load_planes(abc + 2 * vs, n, i);
+  const Fr29 q = Fr29::mul2(a, b, c.neg(), one) * Fr29::unpack(z_inv.v);
+  store_planes(abc, n, i, q);
+}
+
+// LibsnarkReduction, last step: the inverse coset DIF left coefficient j at position bitrev(j)
+__global__ void __launch_bounds__(256) k_libsnark_finish(const int32_t* planes, int k, U256* h_canon,
+                                                         Fr* h_mont, uint32_t n) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t pos = k ? (__brev(j) >> (32 - k)) : 0u;
+  const Fr29 h = load_planes(planes, n, pos);
+  if (h_mont) h_mont[j] = h.to_mont256();
+  if (h_canon) {
+    f29::L9 uno{};
+    uno.v[0] = 1;
+    const Fr29 x = (h * Fr29::from_limbs(uno)).canonical();
+    U256 u;
+    x.pack(u.v);
+    h_canon[j] = u;
+  }
+}
+
 // (A_i . w)(B_i . w) == C_i . w for every row; records the smallest failing row
 __global__ void __launch_bounds__(256) k_check_rows(CsrDev A, CsrDev B, CsrDev C, const Fr* w,
                                                     uint32_t m, unsigned long long* first_bad) {
@@ -120,9 +151,11 @@ long long check_satisfied(const CsrHost& A, const CsrHost& B, const CsrHost& C, 
   return out == none ? -1 : (long long)out;
 }
 
-void WitnessMap::init(const CsrHost& A, const CsrHost& B, uint32_t m_, uint32_t num_inputs_) {
+void WitnessMap::init(const CsrHost& A, const CsrHost& B, uint32_t m_, uint32_t num_inputs_,
+                      int reduction_) {
   m = m_;
   num_inputs = num_inputs_;
+  reduction = reduction_;
   uint64_t need = (uint64_t)m + num_inputs;
   int k = 0;
   while (((uint64_t)1 << k) < need) ++k;
@@ -130,6 +163,14 @@ void WitnessMap::init(const CsrHost& A, const CsrHost& B, uint32_t m_, uint32_t 
   if (k + 1 > 28) throw std::runtime_error("PolynomialDegreeTooLarge");
   plan.build(k, nullptr);
   n = (uint32_t)plan.n();
+  if (reduction == 1) {
+    // ark-groth16 LibsnarkReduction: coset g * H with g = Fr::GENERATOR = 5
+    const Fr g = Fr::from_u32(5), gi = g.inv();
+    plan.make_twist(g, plan.base.n_inv, cs_lo, cs_hi);
+    plan.make_twist(gi, plan.base.n_inv, ci_lo, ci_hi);
+    const Fr z = fr_pow_u64(g, n) - Fr::one();  // Z_H on the coset: g^n - 1
+    Fr29::from_mont256(z.inv()).pack_internal(z_inv_packed.v);
+  }
   auto up = [&](const CsrHost& h, CsrStore& d) {
     d.rowptr.alloc((size_t)m + 1);
     d.col.alloc(h.nnz ? h.nnz : 1);
@@ -150,6 +191,17 @@ void WitnessMap::run(const Fr* w_dev, U256* h_canon, Fr* h_mont, hipStream_t str
   CsrDev B{dB.rowptr.p, dB.col.p, dB.val.p};
   const size_t vs = (size_t)NTT29_LIMBS * n;
   G16_LAUNCH(k_spmv_abc, ceil_div(n, 256), 256, 0, stream, A, B, w_dev, m, num_inputs, n, abc.p);
+  if (reduction == 1) {
+    // LibsnarkReduction::witness_map_from_matrices (ark-groth16; call sites reference
+    // tests/groth16.rs:25-35): ifft, coset fft with g = 5, (a b - c) / Z, inverse coset fft
+    ntt29_dif(plan, abc.p, vs, 3, /*inverse=*/true, NTT_FUSE_TWIST_SCALE, stream, cs_lo.p, cs_hi.p);
+    ntt29_dit(plan, abc.p, vs, 3, stream);
+    G16_LAUNCH(k_libsnark_quotient, ceil_div(n, 256), 256, 0, stream, abc.p, z_inv_packed, n);
+    ntt29_dif(plan, abc.p, vs, 1, /*inverse=*/true, NTT_FUSE_TWIST_SCALE, stream, ci_lo.p, ci_hi.p);
+    G16_LAUNCH(k_libsnark_finish, ceil_div(n, 256), 256, 0, stream, (const int32_t*)abc.p, plan.base.k,
+               h_canon, h_mont, n);
+    return;
+  }
   ntt29_dif(plan, abc.p, vs, 3, /*inverse=*/true, NTT_FUSE_TWIST_SCALE, stream);
   ntt29_dit(plan, abc.p, vs, 3, stream);
   G16_LAUNCH(k_mul_sub, ceil_div(n, 256), 256, 0, stream, (const int32_t*)abc.p, h_canon, h_mont, n);

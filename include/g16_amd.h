@@ -72,8 +72,20 @@ typedef struct {
   int window_bits; /* MSM window c; <= 0: automatic                                              */
   int planes;      /* stored multiples 2^(c*D*j)P per point; <= 0: as many as fit (full = W)     */
   int dist_wm;     /* world > 1 only: distribute the witness map too (g16_prove_dist_phase*)      */
-  int reserved[2];
+  int reduction;   /* G16_REDUCTION_CIRCOM (0, default) or G16_REDUCTION_LIBSNARK                  */
+  int reserved[1];
 } g16_options;
+
+/* The R1CS -> QAP reduction (the `QAP` type parameter of ark_groth16::Groth16<E, QAP>):
+ *   CIRCOM   = ark_circom::CircomReduction (reference src/circom/qap.rs:12-106): snarkjs keys (.zkey)
+ *   LIBSNARK = ark_groth16::LibsnarkReduction, the default of `Groth16<Bn254>` used with
+ *              arkworks-generated keys (reference tests/groth16.rs:9,25-35; README.md:69-74 explains
+ *              why the two must not be mixed).  Its H query has domain_size - 1 points: pass it
+ *              padded with the point at infinity (all-zero) to domain_size entries.
+ * The matrices handed to g16_ctx_create hold A and B only (as read_zkey produces them,
+ * src/zkey.rs:188-192); c_i = a_i * b_i is used where LibsnarkReduction evaluates C.w, which is
+ * the same value for a satisfying assignment (g16_check_satisfied tests that).                     */
+enum { G16_REDUCTION_CIRCOM = 0, G16_REDUCTION_LIBSNARK = 1 };
 
 #define G16_PROOF_BYTES 256   /* A(64) | B(128) | C(64), affine */
 #define G16_PARTIAL_BYTES 1024 /* A | B1 | B2 | L | H | s*A | r*B1: one rank's sums, XYZZ (x, y, zz, zzz;
@@ -185,6 +197,12 @@ typedef struct g16_setup g16_setup;
 g16_status g16_setup_create(int device, const g16_csr* at, const g16_csr* bt, const g16_csr* ct,
                             uint32_t n_vars, uint32_t n_public, uint32_t num_constraints,
                             const uint64_t* toxic, g16_setup** out);
+/* Same with the reduction named (G16_REDUCTION_*): the H query is CircomReduction's or
+ * LibsnarkReduction's h_query_scalars (the rest of the key is identical: CircomReduction
+ * delegates instance_map_with_evaluation to LibsnarkReduction, src/circom/qap.rs:16-21).          */
+g16_status g16_setup_create_ex(int device, const g16_csr* at, const g16_csr* bt, const g16_csr* ct,
+                               uint32_t n_vars, uint32_t n_public, uint32_t num_constraints,
+                               const uint64_t* toxic, int reduction, g16_setup** out);
 /* host arrays owned by the handle; ic: (n_public+1) x 64 bytes = vk.gamma_abc_g1                  */
 g16_status g16_setup_key(g16_setup* s, g16_key_desc* key, const uint8_t** ic, uint32_t* ic_count,
                          uint8_t gamma_g2[128]);

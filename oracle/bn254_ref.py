@@ -404,6 +404,52 @@ def witness_map_from_matrices(a_rows, b_rows, num_inputs, num_constraints, full_
     return [(x - y) % R_MOD for x, y in zip(ab, c)]            # qap.rs:83-87
 
 
+def witness_map_libsnark(a_rows, b_rows, num_inputs, num_constraints, full_assignment, c_rows=None):
+    """ark-groth16 0.5 LibsnarkReduction::witness_map_from_matrices (un-vendored crate, restated from
+    its published algorithm; the reference reaches it as the default QAP of `Groth16<Bn254>`,
+    tests/groth16.rs:9,25-35): a, b (and c) evaluated on the size-n domain, moved to the coset
+    g * H (g = Fr::GENERATOR = 5), h = (a b - c) / Z_H on the coset, inverse coset FFT.
+    Returns the n coefficients of h (the top one is 0).  c_rows=None: c_i = a_i b_i, which is what
+    C . w equals for a satisfying assignment."""
+    n = domain_size_for(num_constraints + num_inputs)
+    if n is None:
+        raise ValueError("PolynomialDegreeTooLarge")
+    a = [0] * n
+    b = [0] * n
+    c = [0] * n
+    for i in range(num_constraints):
+        a[i] = evaluate_constraint(a_rows[i], full_assignment)
+        b[i] = evaluate_constraint(b_rows[i], full_assignment)
+        c[i] = a[i] * b[i] % R_MOD if c_rows is None else evaluate_constraint(c_rows[i], full_assignment)
+    for i in range(num_inputs):
+        a[num_constraints + i] = full_assignment[i] % R_MOD
+    g = FR_GENERATOR
+
+    def to_coset(v):
+        v = ntt(v, inverse=True)
+        pw = 1
+        for i in range(n):
+            v[i] = v[i] * pw % R_MOD
+            pw = pw * g % R_MOD
+        return ntt(v)
+
+    a, b, c = to_coset(a), to_coset(b), to_coset(c)
+    z_inv = fr_inv((pow(g, n, R_MOD) - 1) % R_MOD)             # 1 / Z_H(g w^i), constant on the coset
+    h = [(x * y - z) * z_inv % R_MOD for x, y, z in zip(a, b, c)]
+    h = ntt(h, inverse=True)
+    gi = fr_inv(g)
+    pw = 1
+    for i in range(n):
+        h[i] = h[i] * pw % R_MOD
+        pw = pw * gi % R_MOD
+    return h
+
+
+def h_query_scalars_libsnark(max_power, t, zt, delta_inverse):
+    """ark-groth16 LibsnarkReduction::h_query_scalars: zt / delta * t^i for i < max_power."""
+    return [zt * delta_inverse % R_MOD * pow(t, i, R_MOD) % R_MOD for i in range(max_power)]
+
+
 def h_query_scalars(max_power, t, delta_inverse):
     """reference src/circom/qap.rs:90-105."""
     scalars = [delta_inverse * pow(t, i, R_MOD) % R_MOD for i in range(2 * max_power + 1)]
@@ -630,11 +676,16 @@ def create_proof_with_assignment(pk, r, s, h, input_assignment, aux_assignment):
 
 
 def create_proof_with_reduction_and_matrices(pk, r, s, matrices, num_inputs, num_constraints,
-                                             full_assignment):
-    """Groth16::<Bn254,CircomReduction>::create_proof_with_reduction_and_matrices, argument order as
-    at reference benches/groth16.rs:52-60 / src/zkey.rs:903-911."""
-    h = witness_map_from_matrices(matrices["a"], matrices["b"], num_inputs, num_constraints,
-                                  full_assignment)
+                                             full_assignment, reduction="circom"):
+    """Groth16::<Bn254,QAP>::create_proof_with_reduction_and_matrices, argument order as at reference
+    benches/groth16.rs:52-60 / src/zkey.rs:903-911.  QAP = CircomReduction (default) or
+    LibsnarkReduction (reduction="libsnark": the `Groth16<Bn254>` of reference tests/groth16.rs:9)."""
+    if reduction == "libsnark":
+        h = witness_map_libsnark(matrices["a"], matrices["b"], num_inputs, num_constraints,
+                                 full_assignment, matrices.get("c"))
+    else:
+        h = witness_map_from_matrices(matrices["a"], matrices["b"], num_inputs, num_constraints,
+                                      full_assignment)
     return create_proof_with_assignment(pk, r, s, h, full_assignment[1:num_inputs],
                                         full_assignment[num_inputs:])
 
@@ -770,9 +821,12 @@ def lagrange_at_tau(n, tau):
     return ntt([pow(tau, i, R_MOD) for i in range(n)], inverse=True)
 
 
-def trapdoor_setup(constraints, n_vars, n_public, tau, alpha, beta, gamma, delta):
+def trapdoor_setup(constraints, n_vars, n_public, tau, alpha, beta, gamma, delta, reduction="circom"):
     """constraints: list of (A,B,C) rows, each a list of (wire, coeff) as in the .r1cs file.
-    Returns a pk dict shaped like read_zkey's (plus the scalar-side trapdoor data under 'td')."""
+    Returns a pk dict shaped like read_zkey's (plus the scalar-side trapdoor data under 'td').
+    reduction: "circom" (CircomReduction::h_query_scalars, qap.rs:90-105) or "libsnark" (arkworks'
+    default QAP, reference tests/groth16.rs:25); the libsnark H query has n - 1 entries and is
+    padded with the point at infinity to n."""
     m = len(constraints)
     num_inputs = n_public + 1
     n = domain_size_for(m + num_inputs)
@@ -792,7 +846,11 @@ def trapdoor_setup(constraints, n_vars, n_public, tau, alpha, beta, gamma, delta
     gi, di = fr_inv(gamma), fr_inv(delta)
     k_ic = [(beta * u[i] + alpha * v[i] + w[i]) * gi % R_MOD for i in range(num_inputs)]
     k_l = [(beta * u[i] + alpha * v[i] + w[i]) * di % R_MOD for i in range(num_inputs, n_vars)]
-    k_h = h_query_scalars(n - 1, tau, di)
+    if reduction == "libsnark":
+        zt = (pow(tau, n, R_MOD) - 1) % R_MOD
+        k_h = h_query_scalars_libsnark(n - 1, tau, zt, di) + [0]
+    else:
+        k_h = h_query_scalars(n - 1, tau, di)
     g1m = lambda k: G1.mul(G1_GEN, k)
     g2m = lambda k: G2.mul(G2_GEN, k)
     pk = dict(

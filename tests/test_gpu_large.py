@@ -202,3 +202,32 @@ def test_dense_skewed_circuit_2p14_vs_cpu_restatement(gpulib, tmp_path):
     proof = cc.Prover(pk2, mats2).prove(rs[0], rs[1], wm)
     want = cpu_ref.prove(pk2, mats2, rs[0:1].copy(), rs[1:2].copy(), wm)
     assert proof.raw == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logm", [16])
+def test_libsnark_reduction_large_pairing(gpulib, logm):
+    """arkworks-style key (LibsnarkReduction, reference tests/groth16.rs path) at 2^16: multi-pass
+    coset NTTs + the 7th inverse transform; the proof verifies, a wrong public input is rejected,
+    and the key's H query really is Z(tau)/delta * tau^i (spot checks against the oracle)."""
+    import circom_compat_amd as cc
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    mats, (A, B, Cm), w_ints, n_vars = bench.chain_circuit(cc, logm)
+    rng = random.Random(logm + 7)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox, reduction="libsnark")
+    n = pk.domain_size
+    tau, delta = tox[0], tox[4]
+    zt = (pow(tau, n, o.R_MOD) - 1) % o.R_MOD
+    for i in (0, 1, 12345, n - 2):
+        k = zt * o.fr_inv(delta) % o.R_MOD * pow(tau, i, o.R_MOD) % o.R_MOD
+        assert bytes(pk.h_query[i]) == o.g1_to_bytes(o.G1.mul(o.G1_GEN, k))
+    assert not pk.h_query[n - 1].any()                      # padding: the point at infinity
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    proof = cc.Prover(pk, mats, reduction="libsnark").prove(r, s, w_ints)
+    vk = dict(alpha_g1=o.g1_from_bytes(bytes(pk.vk.alpha_g1)), beta_g2=o.g2_from_bytes(bytes(pk.vk.beta_g2)),
+              gamma_g2=o.g2_from_bytes(bytes(pk.vk.gamma_g2)), delta_g2=o.g2_from_bytes(bytes(pk.vk.delta_g2)),
+              ic=[o.g1_from_bytes(bytes(x)) for x in pk.vk.gamma_abc_g1])
+    assert o.verify_proof(vk, [w_ints[1]], H.proof_from_bytes(proof.raw))
+    assert not o.verify_proof(vk, [(w_ints[1] + 1) % o.R_MOD], H.proof_from_bytes(proof.raw))

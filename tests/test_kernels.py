@@ -277,3 +277,64 @@ def test_dense_skewed_circuit_through_zkey_writer_and_loader(lib, tmp_path):
     assert o.verify_proof(opk, w[1:2], want)
     proof = cc.Groth16.create_proof_with_reduction_and_matrices(pk2, r, s, mats2, 2, len(cons), w, lib=lib)
     assert proof.raw == o.proof_to_bytes(want)
+
+
+# ---- LibsnarkReduction (arkworks-generated keys): reference tests/groth16.rs ---------------------
+def _fixture(golden, name):
+    import json
+    r1 = o.read_r1cs(open(os.path.join(golden, name + ".r1cs"), "rb").read())
+    if name == "mycircuit":
+        w = [1, 33, 3, 11]
+    else:
+        w = [int(x) for x in json.load(open(os.path.join(golden, "safe-circuit-witness.json")))]
+    return r1, w
+
+
+@pytest.mark.parametrize("name", ["mycircuit", "circuit2"])
+def test_libsnark_witness_map_vs_oracle(lib, golden, name):
+    """LibsnarkReduction::witness_map_from_matrices on the reference's circuits: h coefficients equal
+    the oracle's restatement, value for value"""
+    import circom_compat_amd as cc
+    r1, w = _fixture(golden, name)
+    cons = r1["constraints"]
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    want = o.witness_map_libsnark(a_rows, b_rows, r1["num_inputs"], len(cons), w)
+    mats = H.matrices_from_rows(a_rows, b_rows, r1["num_inputs"], r1["n_wires"], lib)
+    got = cc.LibsnarkReduction.witness_map_from_matrices(mats, r1["num_inputs"], len(cons), w, lib=lib)
+    assert H.fr_from_mont_arr(got) == want
+    # and CircomReduction on the same matrices is a different vector (README.md:69-74: do not mix)
+    got_c = cc.CircomReduction.witness_map_from_matrices(mats, r1["num_inputs"], len(cons), w, lib=lib)
+    assert H.fr_from_mont_arr(got_c) == o.witness_map_from_matrices(a_rows, b_rows, r1["num_inputs"], len(cons), w)
+    assert H.fr_from_mont_arr(got_c) != want
+
+
+@pytest.mark.parametrize("name", ["mycircuit", "circuit2"])
+def test_groth16_libsnark_setup_prove_verify(lib, golden, name):
+    """reference tests/groth16.rs:11-40 (mycircuit) and :75-104 (circuit2): generate parameters with
+    the default (Libsnark) reduction, prove, verify; :42-73: a wrong public input is rejected.
+    Key and proof are also compared with the oracle's byte for byte."""
+    import circom_compat_amd as cc
+    r1, w = _fixture(golden, name)
+    cons = r1["constraints"]
+    r1cs = cc.R1CS.from_file(os.path.join(golden, name + ".r1cs"), lib)
+    rng = random.Random(2024)
+    pk = cc.Groth16.generate_random_parameters_with_reduction(r1cs, rng, lib=lib)       # libsnark
+    rng2 = random.Random(2024)
+    tox = [rng2.randrange(1, o.R_MOD) for _ in range(5)]
+    opk = o.trapdoor_setup(cons, r1["n_wires"], r1["num_inputs"] - 1, *tox, reduction="libsnark")
+    assert bytes(pk.h_query.tobytes()) == b"".join(o.g1_to_bytes(p) for p in opk["h_query"])
+    assert bytes(pk.a_query.tobytes()) == b"".join(o.g1_to_bytes(p) for p in opk["a_query"])
+    mats = r1cs.matrices()
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    proof = cc.Groth16.create_proof_with_reduction_and_matrices(
+        pk, r, s, mats, mats.num_instance_variables, mats.num_constraints, w, lib=lib)
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), r1["num_inputs"],
+                                                      len(cons), w, reduction="libsnark")
+    assert proof.raw == o.proof_to_bytes(want)
+    pub = w[1:r1["num_inputs"]]
+    assert o.verify_proof(opk, pub, H.proof_from_bytes(proof.raw))
+    assert not o.verify_proof(opk, [(pub[0] + 1) % o.R_MOD] + pub[1:], H.proof_from_bytes(proof.raw))
+    # a circom-reduction proof does not verify under a libsnark key
+    bad = cc.Prover(pk, mats, lib=lib, reduction="circom").prove(r, s, w)
+    assert not o.verify_proof(opk, pub, H.proof_from_bytes(bad.raw))
