@@ -59,8 +59,6 @@ struct g16_ctx {
   DevBuf<FinTables> fin_tab;
   DevBuf<FinScratch> fin_scr;
   DevBuf<uint8_t> out_dev;  // proof (256) | partial (384) | gathered partials
-  DevBuf<G1Affine> aff1;
-  DevBuf<G2Affine> aff2;
 
   StageTimer timer;
   float st_ms[ST_COUNT] = {0};
@@ -166,7 +164,7 @@ void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   G16_HIP(hipEventRecord(c->ev_w, s));  // w is resident (upload enqueued on the main stream)
   G16_HIP(hipStreamWaitEvent(x, c->ev_w, 0));
-  int id = tm ? tm->begin(ST_WITNESS_NTT, x) : -1;
+  int id = tm ? tm->begin(ST_WITNESS_MAP, x) : -1;
   c->wm.run(w_dev, c->h_canon.p, nullptr, x);
   if (tm) tm->end(id, x);
   id = tm ? tm->begin(ST_MSM_SORT, x) : -1;
@@ -295,8 +293,6 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     c->fin_tab.alloc(1);
     c->fin_scr.alloc(1);
     c->out_dev.alloc(G16_PROOF_BYTES + G16_PARTIAL_BYTES * (size_t)(c->world + 1));
-    c->aff1.alloc(1);
-    c->aff2.alloc(1);
 
     // MSM configurations: the four witness queries share one sort, hence one (c, W, planes)
     const size_t reserve = (size_t)3 << 30;
@@ -652,9 +648,8 @@ g16_status g16_stage_times(g16_ctx* c, float ms[G16_N_STAGES], uint32_t launches
 }
 
 const char* g16_stage_name(int stage) {
-  static const char* names[ST_COUNT] = {"witness_spmv",  "witness_map",        "witness_pointwise",
-                                        "msm_sort",      "msm_accumulate_g1",  "msm_accumulate_g2",
-                                        "msm_reduce",    "finalize"};
+  static const char* names[ST_COUNT] = {"witness_map",       "msm_sort",   "msm_accumulate_g1",
+                                        "msm_accumulate_g2", "msm_reduce", "finalize"};
   return (stage >= 0 && stage < ST_COUNT) ? names[stage] : "?";
 }
 

@@ -74,12 +74,10 @@ struct DevBuf {
 // per-stage HIP-event timing (bench.py reads it through g16_stage_times; off by default)
 // ------------------------------------------------------------------------------------------------
 enum Stage {
-  ST_WITNESS_SPMV = 0,
-  ST_WITNESS_NTT,
-  ST_WITNESS_POINTWISE,
+  ST_WITNESS_MAP = 0,  // sparse mat-vec + the six NTTs + pointwise (aux stream)
   ST_MSM_SORT,
-  ST_MSM_ACC_G1,   // k_bucket_accumulate<Fq>  -- the dominant kernel
-  ST_MSM_ACC_G2,   // k_bucket_accumulate<Fq2>
+  ST_MSM_ACC_G1,  // k_bucket_accumulate<Fq>  -- the dominant kernel
+  ST_MSM_ACC_G2,  // k_bucket_accumulate<Fq2>
   ST_MSM_REDUCE,
   ST_FINALIZE,
   ST_COUNT

@@ -123,8 +123,6 @@ template <class F>
 void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, MsmAcc<F>* out_dev,
                 hipStream_t stream, StageTimer* tm = nullptr);
 
-// Fr Montgomery -> canonical (ark-ff into_bigint), n elements
-void fr_to_canonical(const Fr* in, U256* out, uint32_t n, hipStream_t stream);
 
 
 }  // namespace g16

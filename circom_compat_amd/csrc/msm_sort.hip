@@ -44,11 +44,6 @@ MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
 
 namespace {
 
-__global__ void __launch_bounds__(256) k_fr_to_canonical(const Fr* in, U256* out, uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  out[i] = in[i].to_canonical();
-}
 
 // Walks the signed c-bit digits of canonical scalar i; emit(g, entry) for every non-zero digit.
 template <class Emit>
@@ -329,9 +324,6 @@ __global__ void __launch_bounds__(256) k_find_large(const uint32_t* offset, uint
 
 }  // namespace
 
-void fr_to_canonical(const Fr* in, U256* out, uint32_t n, hipStream_t stream) {
-  if (n) G16_LAUNCH(k_fr_to_canonical, ceil_div(n, 256), 256, 0, stream, in, out, n);
-}
 
 void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   cfg = c;
