@@ -338,3 +338,31 @@ def test_groth16_libsnark_setup_prove_verify(lib, golden, name):
     # a circom-reduction proof does not verify under a libsnark key
     bad = cc.Prover(pk, mats, lib=lib, reduction="circom").prove(r, s, w)
     assert not o.verify_proof(opk, pub, H.proof_from_bytes(bad.raw))
+
+
+def test_error_paths_through_the_abi(lib, golden):
+    """errors are status codes + messages, never exceptions across the boundary: wrong witness
+    length, unknown reduction, distributed witness map on a non-power-of-two world, partial-only
+    entry points on the wrong kind of ctx"""
+    import circom_compat_amd as cc
+    pk, mats = cc.read_zkey(os.path.join(golden, "test.zkey"), lib)
+    pr = cc.Prover(pk, mats, lib=lib)
+    with pytest.raises(cc.G16Error) as e:
+        pr.prove(1, 2, [1, 33, 3])                      # n_vars is 4
+    assert "witness length" in str(e.value)
+    with pytest.raises(cc.G16Error):
+        pr.prove_finish(1, 2, bytes(2 * 1024))          # world mismatch (ctx world = 1)
+    assert pr.exchange_bytes() == 0                     # not a dist_wm ctx
+    with pytest.raises(cc.G16Error):
+        pr.dist_phase2(0, 0)
+    opt_bad = dict(lib=lib, rank=0, world=3, dist_wm=True)
+    with pytest.raises(cc.G16Error) as e:
+        cc.Prover(pk, mats, **opt_bad)
+    assert "power-of-two" in str(e.value)
+    with pytest.raises(KeyError):
+        cc.Prover(pk, mats, lib=lib, reduction="pinocchio")
+    # a proving ctx refuses more scalars than it has points for
+    with pytest.raises(cc.G16Error):
+        pr.msm_g1(0, [1] * 10)
+    # and the prover still works after the failed calls
+    assert len(pr.prove(1, 2, [1, 33, 3, 11]).raw) == 256
