@@ -32,7 +32,9 @@ struct g16_ctx {
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;  // finalize stages that overlap the MSMs
   hipStream_t aux = nullptr;   // witness map + H-query sort, beside the witness-scalar MSMs
-  hipEvent_t ev_start = nullptr, ev_ab = nullptr, ev_side = nullptr, ev_w = nullptr, ev_h = nullptr;
+  hipStream_t red = nullptr;   // G2 bucket reduction, underneath the H MSM
+  hipEvent_t ev_start = nullptr, ev_ab = nullptr, ev_side = nullptr, ev_w = nullptr, ev_h = nullptr,
+             ev_b2 = nullptr;
   std::string err;
 
   WitnessMap wm;
@@ -144,7 +146,17 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
     after_ab();
     msm_run<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, &S->L, s, tm);
   }
-  msm_run<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, &S->B2, s, tm);
+  // B2: accumulate here; with small bucket sets its reduction (a latency-bound chain of Fq2 point
+  // additions) runs on its own stream underneath the H MSM -- with large ones it would only take
+  // VALU slots from it (measured at 2^22: 41.5 vs 40.1 ms).  ev_side = "everything forked is done".
+  msm_accumulate<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, 0, s, tm);
+  hipStream_t rs = (c->overlap && c->cfg_w.nb() < (1u << 18)) ? c->red : s;
+  G16_HIP(hipEventRecord(c->ev_b2, s));
+  G16_HIP(hipStreamWaitEvent(rs, c->ev_b2, 0));
+  msm_reduce<Fq2>(c->sort_w, c->work2, 0, 1, &S->B2, rs, tm);
+  G16_HIP(hipEventRecord(c->ev_b2, rs));
+  G16_HIP(hipStreamWaitEvent(c->side, c->ev_b2, 0));  // the side stream joins it: one event to wait on
+  G16_HIP(hipEventRecord(c->ev_side, c->side));
 }
 
 // main stream: H MSM once the aux stream has produced (and sorted) this rank's h scalars
@@ -231,6 +243,7 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
   g16_status st = guarded(c, [&]() -> g16_status {
     G16_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     G16_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    G16_HIP(hipStreamCreateWithFlags(&c->red, hipStreamNonBlocking));
     {
       // the aux stream carries the memory/atomic-bound work that should slip in beside the
       // ALU-bound MSM kernels: give its workgroups dispatch priority
@@ -246,6 +259,7 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     G16_HIP(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_ab, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    G16_HIP(hipEventCreateWithFlags(&c->ev_b2, hipEventDisableTiming));
     hipStream_t s = c->stream;
     c->N = key->n_vars;
     c->p = key->n_public;
@@ -371,6 +385,10 @@ void g16_ctx_destroy(g16_ctx* c) {
     (void)hipStreamSynchronize(c->aux);
     (void)hipStreamDestroy(c->aux);
   }
+  if (c->red) {
+    (void)hipStreamSynchronize(c->red);
+    (void)hipStreamDestroy(c->red);
+  }
   if (c->ev_w) (void)hipEventDestroy(c->ev_w);
   if (c->ev_h) (void)hipEventDestroy(c->ev_h);
   if (c->stream) {
@@ -380,6 +398,7 @@ void g16_ctx_destroy(g16_ctx* c) {
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_ab) (void)hipEventDestroy(c->ev_ab);
   if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+  if (c->ev_b2) (void)hipEventDestroy(c->ev_b2);
   delete c;
 }
 
@@ -474,7 +493,6 @@ g16_status g16_prove_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], 
       G16_HIP(hipEventRecord(c->ev_ab, s));
       G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
       fin_var(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->fin_scr.p, c->out_dev.p, c->side);
-      G16_HIP(hipEventRecord(c->ev_side, c->side));
     });
     G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));  // join
     int id = c->timer.enabled ? c->timer.begin(ST_FINALIZE, s) : -1;
@@ -514,7 +532,6 @@ g16_status g16_prove_partial_dev(g16_ctx* c, const uint64_t r[4], const uint64_t
       G16_HIP(hipEventRecord(c->ev_ab, s));
       G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
       fin_partial_var(c->sums_dev.p, c->rs_dev.p, c->side);
-      G16_HIP(hipEventRecord(c->ev_side, c->side));
     });
     G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));
     uint8_t* part = c->out_dev.p + G16_PROOF_BYTES;
@@ -588,7 +605,6 @@ g16_status g16_prove_dist_phase1(g16_ctx* c, const uint64_t r[4], const uint64_t
       G16_HIP(hipEventRecord(c->ev_ab, s));
       G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
       fin_partial_var(c->sums_dev.p, c->rs_dev.p, c->side);
-      G16_HIP(hipEventRecord(c->ev_side, c->side));
     });
     G16_HIP(hipStreamSynchronize(x));  // send buffer complete; the main stream keeps running
     return G16_OK;
