@@ -51,7 +51,7 @@ struct g16_ctx {
   MsmSort sort_w, sort_h;
   MsmPoints<Fq> ptsA, ptsB1, ptsL, ptsH;
   MsmPoints<Fq2> ptsB2;
-  MsmWork<Fq> work1;
+  MsmWork<Fq> work1, workH;  // witness-scalar G1 MSMs (A, B1, L) / H MSM
   MsmWork<Fq2> work2;
 
   DevBuf<Fr> w_dev, h_dev, rs_dev;  // h_dev: storage form (g16_witness_map / g16_msm_g1 staging)
@@ -159,12 +159,14 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
   G16_HIP(hipEventRecord(c->ev_side, c->side));
 }
 
-// main stream: H MSM once the aux stream has produced (and sorted) this rank's h scalars
+// main stream: H MSM once the aux stream has produced (and sorted) this rank's h scalars.
+// (Keeping the whole H chain on the aux stream, in parallel with the witness-scalar chain, was
+// measured on one box at 2^14..2^22: 1-5 % slower at small sizes, neutral at large ones.)
 void enqueue_h_msm(g16_ctx* c) {
   hipStream_t s = c->stream;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   G16_HIP(hipStreamWaitEvent(s, c->ev_h, 0));
-  msm_run<Fq>(c->sort_h, c->ptsH, 0, c->work1, &c->sums_dev.p->H, s, tm);
+  msm_run<Fq>(c->sort_h, c->ptsH, 0, c->workH, &c->sums_dev.p->H, s, tm);
 }
 
 // MSMs of one proof on this ctx's shard; results left in sums_dev.
@@ -335,14 +337,14 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
       c->ptsH.init((const G1Affine*)key->h_query + c->h_lo, lh, c->cfg_h, s);
     }
 
-    // one workspace per curve, large enough for either sort
+    // workspaces: G1 over the witness sort (3 slots when the reductions are batched), G1 over the h
+    // sort, G2 over the witness sort
     {
       const uint32_t nc_w = ceil_div(c->cfg_w.B, msm_red_chunk(c->cfg_w)) * c->cfg_w.D;
       const uint32_t nc_h = ceil_div(c->cfg_h.B, msm_red_chunk(c->cfg_h)) * c->cfg_h.D;
       const uint32_t slots_w = c->cfg_w.nb() + c->cfg_w.lanes, slots_h = c->cfg_h.nb() + c->cfg_h.lanes;
-      const uint32_t mt = slots_w > slots_h ? slots_w : slots_h;
-      const int dmax = c->cfg_w.D > c->cfg_h.D ? c->cfg_w.D : c->cfg_h.D;
-      c->work1.init(mt, nc_w > nc_h ? nc_w : nc_h, dmax, /*batch=*/c->cfg_w.nb() < (1u << 18) ? 3 : 1);
+      c->work1.init(slots_w, nc_w, c->cfg_w.D, /*batch=*/c->cfg_w.nb() < (1u << 18) ? 3 : 1);
+      c->workH.init(slots_h, nc_h, c->cfg_h.D, 1);
       c->work2.init(slots_w, nc_w, c->cfg_w.D);
     }
 
@@ -455,7 +457,7 @@ static g16_status msm_common(g16_ctx* c, int which, bool g2, const uint64_t* sca
       msm_run<Fq2>(*sort, c->ptsB2, 0, c->work2, &c->sums_dev.p->B2, s, nullptr);
     } else {
       // for L the entry index is already the l_query index here (scalars pair with l_query[i])
-      msm_run<Fq>(*sort, *P1, 0, c->work1, &c->sums_dev.p->A, s, nullptr);
+      msm_run<Fq>(*sort, *P1, 0, sort == &c->sort_h ? c->workH : c->work1, &c->sums_dev.p->A, s, nullptr);
     }
     sums_to_affine(c->sums_dev.p, c->out_dev.p, s);  // A -> bytes [0,64), B2 -> [128,256)
     G16_HIP(hipMemcpyAsync(out, c->out_dev.p + (g2 ? 128 : 0), g2 ? 128 : 64,
