@@ -127,7 +127,11 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
   int id = tm ? tm->begin(ST_MSM_SORT, s) : -1;
   c->sort_w.run(w_dev + 1 + c->w_lo, c->w_hi - c->w_lo, /*mont=*/true, s);
   if (tm) tm->end(id, s);
-  if (c->cfg_w.nb() < (1u << 18)) {
+  // A/B knobs (measurement only): G16_BATCH_REDUCE / G16_B2_RED_STREAM = 0 | 1 override the size rules
+  static const int knob_batch = [] { const char* e = getenv("G16_BATCH_REDUCE"); return e ? atoi(e) : -1; }();
+  static const int knob_b2 = [] { const char* e = getenv("G16_B2_RED_STREAM"); return e ? atoi(e) : -1; }();
+  const bool small = c->cfg_w.nb() < (1u << 18);
+  if ((knob_batch < 0 ? small : knob_batch != 0) && c->work1.batch >= 3) {
     // A, B1, L share the witness sort: three accumulations, ONE batched bucket reduction.  With
     // few buckets the reduction is pure latency (~0.4 ms of dependent EC additions whatever the
     // size): paying it once instead of three times is worth 20 % of a 2^16 proof and of a rank's
@@ -147,10 +151,12 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
     msm_run<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, &S->L, s, tm);
   }
   // B2: accumulate here; with small bucket sets its reduction (a latency-bound chain of Fq2 point
-  // additions) runs on its own stream underneath the H MSM -- with large ones it would only take
-  // VALU slots from it (measured at 2^22: 41.5 vs 40.1 ms).  ev_side = "everything forked is done".
+  // additions) runs on its own stream underneath the H MSM -- with large ones it only takes VALU
+  // slots from it.  Measured on one box, batched reduction / own stream for the B2 reduction:
+  //   2^14: 4.60 ms neither, 3.84 batched, 3.64 both;  2^18: 6.74 / 5.61 / 5.23;
+  //   2^20: 13.56 / 13.05 / 13.21;  2^22: 40.1 / 41.9 / -.   ev_side = "everything forked is done".
   msm_accumulate<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, 0, s, tm);
-  hipStream_t rs = (c->overlap && c->cfg_w.nb() < (1u << 18)) ? c->red : s;
+  hipStream_t rs = (c->overlap && (knob_b2 < 0 ? c->cfg_w.nb() < (1u << 16) : knob_b2 != 0)) ? c->red : s;
   G16_HIP(hipEventRecord(c->ev_b2, s));
   G16_HIP(hipStreamWaitEvent(rs, c->ev_b2, 0));
   msm_reduce<Fq2>(c->sort_w, c->work2, 0, 1, &S->B2, rs, tm);
@@ -343,7 +349,7 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
       const uint32_t nc_w = ceil_div(c->cfg_w.B, msm_red_chunk(c->cfg_w)) * c->cfg_w.D;
       const uint32_t nc_h = ceil_div(c->cfg_h.B, msm_red_chunk(c->cfg_h)) * c->cfg_h.D;
       const uint32_t slots_w = c->cfg_w.nb() + c->cfg_w.lanes, slots_h = c->cfg_h.nb() + c->cfg_h.lanes;
-      c->work1.init(slots_w, nc_w, c->cfg_w.D, /*batch=*/c->cfg_w.nb() < (1u << 18) ? 3 : 1);
+      c->work1.init(slots_w, nc_w, c->cfg_w.D, /*batch=*/(c->cfg_w.nb() < (1u << 18) || getenv("G16_BATCH_REDUCE")) ? 3 : 1);
       c->workH.init(slots_h, nc_h, c->cfg_h.D, 1);
       c->work2.init(slots_w, nc_w, c->cfg_w.D);
     }
