@@ -90,8 +90,115 @@ __global__ void __launch_bounds__(FIN_T) k_fin_fixed(const FinTables* tab, const
   }
 }
 
-// k * P, 4-bit fixed windows, MSB first; table in LDS (one lane works, latency-bound by design:
-// this runs beside the big MSMs)
+// ---- variable-base k * P with the GLV endomorphism of BN254 G1 -------------------------------------
+// phi(x, y) = (beta x, y) = lambda (x, y) with beta^3 = 1 in Fq, lambda^3 = 1 in Fr.  k is split as
+// k = k1 + k2 lambda (mod r) with |k1|, |k2| < 2^127 (lattice basis (A1, -B1), (A2, B2) of
+// {(a, b): a + b lambda = 0 mod r}, rounded quotients through 2^256-scaled reciprocals), so the
+// doubling chain is 128 long instead of 254.  One lane works (latency-bound by design: this runs
+// beside the big MSMs); constants derived and cross-checked with the oracle
+// (tests: every proof byte depends on them).
+namespace glv {
+constexpr uint32_t G1[3] = {0xc7e0b3d7u, 0xd91d232eu, 0x00000002u};                              // round(2^256 B2 / r)
+constexpr uint32_t G2[5] = {0x391eb18eu, 0x7a7bd9d4u, 0xa773d2cfu, 0x4ccef014u, 0x00000002u};    // round(2^256 |B1| / r)
+constexpr uint32_t A1[2] = {0x94d213e3u, 0x89d32568u};
+constexpr uint32_t A2[4] = {0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u};
+constexpr uint32_t NB1[4] = {0x7d4f1128u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u};                // -B1 > 0
+constexpr uint32_t B2[2] = {0x94d213e3u, 0x89d32568u};
+constexpr uint32_t BETA[8] = {0x77fffffeu, 0x57634731u, 0xacdb5c4fu, 0xd4f263f1u,
+                              0xa0d48bacu, 0x59e26bceu, 0x00000000u, 0x00000000u};
+
+// out[0..NA+NB) = a * b (schoolbook, 32-bit limbs)
+template <int NA, int NB>
+__device__ __forceinline__ void mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  for (int i = 0; i < NA + NB; ++i) out[i] = 0;
+  for (int i = 0; i < NA; ++i) {
+    uint64_t c = 0;
+    for (int j = 0; j < NB; ++j) {
+      c += (uint64_t)a[i] * b[j] + out[i + j];
+      out[i + j] = (uint32_t)c;
+      c >>= 32;
+    }
+    out[i + NB] = (uint32_t)c;
+  }
+}
+// acc (8 limbs, mod 2^256) += / -= x (n limbs)
+__device__ __forceinline__ void add_to(uint32_t* acc, const uint32_t* x, int n) {
+  uint64_t c = 0;
+  for (int i = 0; i < 8; ++i) {
+    c += (uint64_t)acc[i] + (i < n ? x[i] : 0u);
+    acc[i] = (uint32_t)c;
+    c >>= 32;
+  }
+}
+__device__ __forceinline__ void sub_from(uint32_t* acc, const uint32_t* x, int n) {
+  uint64_t br = 0;
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t t = (uint64_t)acc[i] - (i < n ? x[i] : 0u) - br;
+    acc[i] = (uint32_t)t;
+    br = (t >> 32) & 1;
+  }
+}
+// |acc| and its sign (two's complement, 256 bits)
+__device__ __forceinline__ bool abs_in_place(uint32_t* acc) {
+  if (!(acc[7] >> 31)) return false;
+  uint64_t c = 1;
+  for (int i = 0; i < 8; ++i) {
+    c += (uint32_t)~acc[i];
+    acc[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  return true;
+}
+
+struct Split {
+  uint32_t k1[8], k2[8];  // magnitudes (< 2^127)
+  bool neg1, neg2;
+};
+
+__device__ Split split(const U256& k) {
+  uint32_t t1[11], t2[13];
+  mul<8, 3>(k.v, G1, t1);
+  mul<8, 5>(k.v, G2, t2);
+  // c = (k * G + 2^255) >> 256: add the rounding bit at limb 7, keep limbs >= 8
+  uint32_t c1[3], c2[5];
+  {
+    uint64_t c = (uint64_t)t1[7] + 0x80000000u;
+    c >>= 32;
+    for (int i = 0; i < 3; ++i) {
+      c += t1[8 + i];
+      c1[i] = (uint32_t)c;
+      c >>= 32;
+    }
+    c = (uint64_t)t2[7] + 0x80000000u;
+    c >>= 32;
+    for (int i = 0; i < 5; ++i) {
+      c += t2[8 + i];
+      c2[i] = (uint32_t)c;
+      c >>= 32;
+    }
+  }
+  Split s;
+  uint32_t p[9];
+  // k1 = k - c1 A1 - c2 A2
+  for (int i = 0; i < 8; ++i) s.k1[i] = k.v[i];
+  mul<3, 2>(c1, A1, p);
+  sub_from(s.k1, p, 5);
+  mul<5, 4>(c2, A2, p);
+  sub_from(s.k1, p, 8);
+  // k2 = c1 |B1| - c2 B2
+  for (int i = 0; i < 8; ++i) s.k2[i] = 0;
+  mul<3, 4>(c1, NB1, p);
+  add_to(s.k2, p, 7);
+  mul<5, 2>(c2, B2, p);
+  sub_from(s.k2, p, 7);
+  s.neg1 = abs_in_place(s.k1);
+  s.neg2 = abs_in_place(s.k2);
+  return s;
+}
+}  // namespace glv
+
+// k * P: 4-bit fixed windows over (k1, k2) jointly, MSB first; multiples 1..15 of P in LDS, the
+// multiples of phi(P) are phi of those (one product by beta)
 __device__ G1XYZZ29 var_mul(const G1XYZZ29& P, const U256& k, G1XYZZ29* tbl) {
   tbl[0] = G1XYZZ29::infinity();
   tbl[1] = P;
@@ -100,11 +207,26 @@ __device__ G1XYZZ29 var_mul(const G1XYZZ29& P, const U256& k, G1XYZZ29* tbl) {
     q.add(P);
     tbl[i] = q;
   }
+  const glv::Split sp = glv::split(k);
+  U256 bu;
+  for (int i = 0; i < 8; ++i) bu.v[i] = glv::BETA[i];
+  const Fq29 beta = Fq29::from_mont256(Fq::from_canonical(bu));
   G1XYZZ29 acc = G1XYZZ29::infinity();
-  for (int w = 63; w >= 0; --w) {
+  for (int w = 31; w >= 0; --w) {
     for (int d = 0; d < 4; ++d) acc.dbl_in_place();
-    const uint32_t nib = (k.v[w >> 3] >> ((w & 7) * 4)) & 15u;
-    if (nib) acc.add(tbl[nib]);
+    const uint32_t n1 = (sp.k1[w >> 3] >> ((w & 7) * 4)) & 15u;
+    const uint32_t n2 = (sp.k2[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (n1) {
+      G1XYZZ29 t = tbl[n1];
+      if (sp.neg1) t = t.neg();
+      acc.add(t);
+    }
+    if (n2) {
+      G1XYZZ29 t = tbl[n2];
+      t.x = t.x * beta;  // phi
+      if (sp.neg2) t = t.neg();
+      acc.add(t);
+    }
   }
   return acc;
 }
