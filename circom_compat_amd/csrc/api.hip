@@ -156,7 +156,10 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
   //   2^14: 4.60 ms neither, 3.84 batched, 3.64 both;  2^18: 6.74 / 5.61 / 5.23;
   //   2^20: 13.56 / 13.05 / 13.21;  2^22: 40.1 / 41.9 / -.   ev_side = "everything forked is done".
   msm_accumulate<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, 0, s, tm);
-  hipStream_t rs = (c->overlap && (knob_b2 < 0 ? c->cfg_w.nb() < (1u << 16) : knob_b2 != 0)) ? c->red : s;
+  // sharded ranks: the main stream is the critical path (the witness-map phases and exchanges hide
+  // under it), so the B2 reduction leaves it whenever the bucket set is small
+  const uint32_t b2_limit = c->world > 1 ? (1u << 18) : (1u << 16);
+  hipStream_t rs = (c->overlap && (knob_b2 < 0 ? c->cfg_w.nb() < b2_limit : knob_b2 != 0)) ? c->red : s;
   G16_HIP(hipEventRecord(c->ev_b2, s));
   G16_HIP(hipStreamWaitEvent(rs, c->ev_b2, 0));
   msm_reduce<Fq2>(c->sort_w, c->work2, 0, 1, &S->B2, rs, tm);
