@@ -34,7 +34,7 @@ struct g16_ctx {
   hipStream_t aux = nullptr;   // witness map + H-query sort, beside the witness-scalar MSMs
   hipStream_t red = nullptr;   // G2 bucket reduction, underneath the H MSM
   hipEvent_t ev_start = nullptr, ev_ab = nullptr, ev_side = nullptr, ev_w = nullptr, ev_h = nullptr,
-             ev_b2 = nullptr;
+             ev_b2 = nullptr, ev_fixed = nullptr;
   std::string err;
 
   WitnessMap wm;
@@ -119,8 +119,8 @@ void collect_times(g16_ctx* c) {
 // main stream: witness-scalar sort, then the A, B1, L, B2 MSMs (ALU bound).  `after_ab` is called
 // once the A and B1 sums are enqueued: the provers fork the variable-base part of the
 // finalisation onto the side stream there.
-template <class Hook>
-void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
+template <class Hook, class Hook2>
+void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 after_b2) {
   hipStream_t s = c->stream;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   ProofSums* S = c->sums_dev.p;
@@ -163,7 +163,12 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
   G16_HIP(hipEventRecord(c->ev_b2, s));
   G16_HIP(hipStreamWaitEvent(rs, c->ev_b2, 0));
   msm_reduce<Fq2>(c->sort_w, c->work2, 0, 1, &S->B2, rs, tm);
+  // what only needs the B2 sum continues on the `red` stream (never on the main stream: it is a
+  // single-lane chain)
   G16_HIP(hipEventRecord(c->ev_b2, rs));
+  if (rs != c->red) G16_HIP(hipStreamWaitEvent(c->red, c->ev_b2, 0));
+  after_b2();
+  G16_HIP(hipEventRecord(c->ev_b2, c->red));
   G16_HIP(hipStreamWaitEvent(c->side, c->ev_b2, 0));  // the side stream joins it: one event to wait on
   G16_HIP(hipEventRecord(c->ev_side, c->side));
 }
@@ -181,8 +186,8 @@ void enqueue_h_msm(g16_ctx* c) {
 // MSMs of one proof on this ctx's shard; results left in sums_dev.
 // aux stream: witness map (integer-ALU bound) then the H-query sort (atomics/HBM bound), beside
 // the main stream's work.
-template <class Hook>
-void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
+template <class Hook, class Hook2>
+void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 after_b2) {
   hipStream_t s = c->stream, x = c->overlap ? c->aux : c->stream;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   G16_HIP(hipEventRecord(c->ev_w, s));  // w is resident (upload enqueued on the main stream)
@@ -194,12 +199,13 @@ void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
   c->sort_h.run(c->h_canon.p + c->h_lo, c->h_hi - c->h_lo, /*mont=*/false, x);
   if (tm) tm->end(id, x);
   G16_HIP(hipEventRecord(c->ev_h, x));
-  enqueue_witness_msms(c, w_dev, after_ab);
+  enqueue_witness_msms(c, w_dev, after_ab, after_b2);
   enqueue_h_msm(c);
 }
 
-void run_msms(g16_ctx* c, const Fr* w_dev) {
-  run_msms(c, w_dev, [] {});
+template <class Hook>
+void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab) {
+  run_msms(c, w_dev, after_ab, [] {});
 }
 
 // sharded provers: upload (r, s) and start the r/s-only fixed-base sums on the side stream
@@ -271,6 +277,7 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     G16_HIP(hipEventCreateWithFlags(&c->ev_ab, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_b2, hipEventDisableTiming));
+    G16_HIP(hipEventCreateWithFlags(&c->ev_fixed, hipEventDisableTiming));
     hipStream_t s = c->stream;
     c->N = key->n_vars;
     c->p = key->n_public;
@@ -410,6 +417,7 @@ void g16_ctx_destroy(g16_ctx* c) {
   if (c->ev_ab) (void)hipEventDestroy(c->ev_ab);
   if (c->ev_side) (void)hipEventDestroy(c->ev_side);
   if (c->ev_b2) (void)hipEventDestroy(c->ev_b2);
+  if (c->ev_fixed) (void)hipEventDestroy(c->ev_fixed);
   delete c;
 }
 
@@ -499,12 +507,20 @@ g16_status g16_prove_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], 
     G16_HIP(hipEventRecord(c->ev_start, s));
     G16_HIP(hipStreamWaitEvent(c->side, c->ev_start, 0));
     fin_fixed(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, c->side);
-    run_msms(c, (const Fr*)w_dev, [&] {
-      // A and B1 are enqueued: g_a, g1_b and the two variable-base products overlap L / B2 / H
-      G16_HIP(hipEventRecord(c->ev_ab, s));
-      G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
-      fin_var(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->fin_scr.p, c->out_dev.p, c->side);
-    });
+    G16_HIP(hipEventRecord(c->ev_fixed, c->side));
+    run_msms(
+        c, (const Fr*)w_dev,
+        [&] {
+          // A and B1 are enqueued: g_a, g1_b and the two variable-base products overlap L / B2 / H
+          G16_HIP(hipEventRecord(c->ev_ab, s));
+          G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
+          fin_var(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->fin_scr.p, c->out_dev.p, c->side);
+        },
+        [&] {
+          // the B2 sum is there: B (assembly + Fq2 inversion) hides under the H MSM
+          G16_HIP(hipStreamWaitEvent(c->red, c->ev_fixed, 0));
+          fin_b(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, c->red);
+        });
     G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));  // join
     int id = c->timer.enabled ? c->timer.begin(ST_FINALIZE, s) : -1;
     fin_final(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, s);
@@ -616,7 +632,7 @@ g16_status g16_prove_dist_phase1(g16_ctx* c, const uint64_t r[4], const uint64_t
       G16_HIP(hipEventRecord(c->ev_ab, s));
       G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
       fin_partial_var(c->sums_dev.p, c->rs_dev.p, c->side);
-    });
+    }, [] {});
     G16_HIP(hipStreamSynchronize(x));  // send buffer complete; the main stream keeps running
     return G16_OK;
   });

@@ -163,10 +163,12 @@ struct XYZZ29 {
     x = X3;
     y = Y3;
   }
-  // x = X/ZZ, y = Y/ZZZ (one inversion), result canonical in the INTERNAL Montgomery form
+  // x = X/ZZ, y = Y/ZZZ (one inversion), result canonical in the INTERNAL Montgomery form.
+  // VARTIME: binary-GCD inversion (single-lane callers only, see f29_inv_vartime)
+  template <bool VARTIME = false>
   G16_HD Aff29<LF> to_affine() const {
     if (is_inf()) return Aff29<LF>{LF::zero(), LF::zero(), true};
-    LF iz3 = f29_inv(zzz);
+    LF iz3 = VARTIME ? f29_inv_vartime(zzz) : f29_inv(zzz);
     LF iz2 = iz3.sqr() * zz.sqr();
     return Aff29<LF>{(x * iz2).canonical(), (y * iz3).canonical(), false};
   }

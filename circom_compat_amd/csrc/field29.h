@@ -122,6 +122,7 @@ struct Consts {
   static constexpr L9 ONE261 = split(shl_mod(ONE256W, 5, MODW));  // the internal "1"
   static constexpr L9 C266 = split(shl_mod(ONE256W, 10, MODW));   // Montgomery-256 -> 261
   static constexpr L9 MOD32 = times(MOD, 32);
+  static constexpr L9 R3 = split(shl_mod(ONE256W, 3 * 261 - 256, MODW));  // 2^(3*261) mod p (inv_vartime)
 };
 
 }  // namespace f29
@@ -462,6 +463,92 @@ G16_HD F29<P> f29_inv(const F29<P>& a) {
   return r;
 }
 
+// a^-1 by the binary extended Euclidean algorithm on the canonical integer (Guide to ECC, Alg.
+// 2.22): ~4x fewer instructions than the Fermat ladder but data-dependent control flow -- for the
+// single-lane affine conversions of the finalisation only (a whole wave running it would diverge;
+// the plane precomputation keeps the uniform f29_inv).  0 -> 0.
+template <class P>
+G16_HD F29<P> f29_inv_vartime(const F29<P>& a) {
+  uint32_t u[8], v[8], x1[8], x2[8];
+  a.canonical().pack(u);
+  uint32_t nz = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    nz |= u[i];
+    v[i] = P::MOD[i];
+    x1[i] = 0;
+    x2[i] = 0;
+  }
+  if (!nz) return F29<P>::zero();
+  x1[0] = 1;
+  auto is_one = [](const uint32_t* t) {
+    uint32_t o = t[0] ^ 1u;
+    for (int i = 1; i < 8; ++i) o |= t[i];
+    return o == 0;
+  };
+  auto shr1 = [](uint32_t* t, uint32_t top) {  // t = (top : t) >> 1
+    for (int i = 0; i < 7; ++i) t[i] = (t[i] >> 1) | (t[i + 1] << 31);
+    t[7] = (t[7] >> 1) | (top << 31);
+  };
+  auto halve_mod = [&](uint32_t* x) {  // x / 2 mod p
+    uint32_t top = 0;
+    if (x[0] & 1u) {
+      uint64_t c = 0;
+      for (int i = 0; i < 8; ++i) {
+        c += (uint64_t)x[i] + P::MOD[i];
+        x[i] = (uint32_t)c;
+        c >>= 32;
+      }
+      top = (uint32_t)c;
+    }
+    shr1(x, top);
+  };
+  auto geq = [](const uint32_t* s, const uint32_t* t) {
+    for (int i = 7; i >= 0; --i)
+      if (s[i] != t[i]) return s[i] > t[i];
+    return true;
+  };
+  auto sub = [](uint32_t* s, const uint32_t* t) {  // s -= t, returns the borrow
+    uint64_t br = 0;
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t d = (uint64_t)s[i] - t[i] - br;
+      s[i] = (uint32_t)d;
+      br = (d >> 32) & 1;
+    }
+    return (uint32_t)br;
+  };
+  auto sub_mod = [&](uint32_t* s, const uint32_t* t) {  // s = s - t mod p
+    if (sub(s, t)) {
+      uint64_t c = 0;
+      for (int i = 0; i < 8; ++i) {
+        c += (uint64_t)s[i] + P::MOD[i];
+        s[i] = (uint32_t)c;
+        c >>= 32;
+      }
+    }
+  };
+  for (int guard = 0; guard < 2048 && !is_one(u) && !is_one(v); ++guard) {
+    while (!(u[0] & 1u)) {
+      shr1(u, 0);
+      halve_mod(x1);
+    }
+    while (!(v[0] & 1u)) {
+      shr1(v, 0);
+      halve_mod(x2);
+    }
+    if (geq(u, v)) {
+      sub(u, v);
+      sub_mod(x1, x2);
+    } else {
+      sub(v, u);
+      sub_mod(x2, x1);
+    }
+  }
+  // plain integer inverse I = a^-1 (of the INTERNAL value a = z 2^261), wanted: z^-1 2^261 = I 2^522
+  const uint32_t(&res)[8] = is_one(u) ? x1 : x2;
+  return F29<P>::unpack(res) * F29<P>::from_limbs(F29<P>::C::R3);
+}
+
 // Fq2 = Fq[i]/(i^2 + 1) over lazy limbs.  Same contracts as F29, per component, with the value
 // bound |a0 b0| + |a1 b1| < 169 p^2 (both components of both operands below ~9 p).
 template <class P>
@@ -497,6 +584,11 @@ template <class P>
 G16_HD F29x2<P> f29_inv(const F29x2<P>& a) {
   // 1 / (c0 + c1 i) = (c0 - c1 i) / (c0^2 + c1^2)
   F29<P> n = f29_inv(F29<P>::mul2(a.c0, a.c0, a.c1, a.c1));
+  return F29x2<P>{a.c0 * n, (a.c1 * n).neg()};
+}
+template <class P>
+G16_HD F29x2<P> f29_inv_vartime(const F29x2<P>& a) {
+  F29<P> n = f29_inv_vartime(F29<P>::mul2(a.c0, a.c0, a.c1, a.c1));
   return F29x2<P>{a.c0 * n, (a.c1 * n).neg()};
 }
 

@@ -7,7 +7,7 @@
 //   g2_b = s*delta2 + b_g2_query[0] + MSM_B2 + beta2
 //   g_c  = s*g_a + r*g1_b - (r*s)*delta1 + MSM_L + MSM_H
 //
-// Split in three kernels so that nothing but two point additions and the affine conversions sit
+// Split in four kernels so that nothing but a few point additions and one affine conversion sit
 // on the critical path of a proof:
 //   fin_fixed  needs only (r, s): r*delta1, s*delta1, rs*delta1, s*delta2 from per-key tables of
 //              2^i * delta (one table entry per scalar bit, tree-summed by a workgroup).  Launched
@@ -15,7 +15,9 @@
 //   fin_var    needs MSM_A, MSM_B1: forms g_a, g1_b, writes A, and runs the two variable-base
 //              multiplications s*g_a, r*g1_b (4-bit windows, one wave each) on the side stream
 //              while the L / B2 / H MSMs run on the main stream.
-//   fin_final  needs everything: g_c and g2_b assembly + the two remaining affine conversions.
+//   fin_b      needs s*delta2 and MSM_B2: g2_b -> B, on its own stream as soon as the B2 reduction
+//              is done (the Fq2 inversion hides under the H MSM).
+//   fin_final  needs everything: g_c assembly + its affine conversion.
 #pragma once
 #include "common.h"
 #include "ec29.h"
@@ -52,6 +54,8 @@ void fin_build_tables(const KeyHeaderDev* key, FinTables* tab, hipStream_t strea
 void fin_fixed(const FinTables* tab, const Fr* rs_dev, FinScratch* scr, hipStream_t stream);
 void fin_var(const KeyHeaderDev* key, const ProofSums* sums, const Fr* rs_dev, FinScratch* scr,
              uint8_t* proof_dev, hipStream_t stream);
+void fin_b(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr, uint8_t* proof_dev,
+           hipStream_t stream);
 void fin_final(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr,
                uint8_t* proof_dev, hipStream_t stream);
 

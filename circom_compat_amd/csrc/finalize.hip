@@ -27,7 +27,7 @@ __device__ __forceinline__ A tree_sum(A v, A* sh) {
 
 template <class F>
 __device__ __forceinline__ Affine<F> to_storage_affine(const XYZZ29<typename Lazy<F>::type>& a) {
-  const auto p = a.to_affine();
+  const auto p = a.template to_affine<true>();  // one lane works here: binary-GCD inversion
   if (p.inf) return Affine<F>::infinity();
   return Affine<F>{p.x.to_mont256(), p.y.to_mont256()};
 }
@@ -246,24 +246,28 @@ __global__ void __launch_bounds__(64) k_fin_var(const KeyHeaderDev* key, const P
   (b == 0 ? scr->sga : scr->rgb) = var_mul(g, k, tbl);
 }
 
-// block 0: g_c -> C      block 1: g2_b -> B
+// g_c -> C (needs every sum)
 __global__ void __launch_bounds__(64) k_fin_final(const KeyHeaderDev* key, const ProofSums* sums,
                                                   const FinScratch* scr, uint8_t* proof) {
   if (threadIdx.x != 0) return;
-  if (blockIdx.x == 0) {
-    G1XYZZ29 c = scr->sga;
-    c.add(scr->rgb);
-    c.add(scr->rsd1.neg());
-    c.add(sums->L);
-    c.add(sums->H);
-    *reinterpret_cast<G1Affine*>(proof + 192) = to_storage_affine<Fq>(c);
-  } else {
-    G2XYZZ29 b = scr->sd2;
-    b.madd(affine_from_mont256<Fq2>(key->b2_0));
-    b.add(sums->B2);
-    b.madd(affine_from_mont256<Fq2>(key->beta2));
-    *reinterpret_cast<G2Affine*>(proof + 64) = to_storage_affine<Fq2>(b);
-  }
+  G1XYZZ29 c = scr->sga;
+  c.add(scr->rgb);
+  c.add(scr->rsd1.neg());
+  c.add(sums->L);
+  c.add(sums->H);
+  *reinterpret_cast<G1Affine*>(proof + 192) = to_storage_affine<Fq>(c);
+}
+
+// g2_b -> B (needs only s * delta2 and the B2 sum: runs as soon as the B2 reduction is done,
+// underneath the H MSM)
+__global__ void __launch_bounds__(64) k_fin_b(const KeyHeaderDev* key, const ProofSums* sums,
+                                              const FinScratch* scr, uint8_t* proof) {
+  if (threadIdx.x != 0) return;
+  G2XYZZ29 b = scr->sd2;
+  b.madd(affine_from_mont256<Fq2>(key->b2_0));
+  b.add(sums->B2);
+  b.madd(affine_from_mont256<Fq2>(key->beta2));
+  *reinterpret_cast<G2Affine*>(proof + 64) = to_storage_affine<Fq2>(b);
 }
 
 // ---- sharded provers ---------------------------------------------------------------------------
@@ -438,7 +442,11 @@ void fin_var(const KeyHeaderDev* key, const ProofSums* sums, const Fr* rs_dev, F
 }
 void fin_final(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr,
                uint8_t* proof_dev, hipStream_t stream) {
-  G16_LAUNCH(k_fin_final, 2, 64, 0, stream, key, sums, scr, proof_dev);
+  G16_LAUNCH(k_fin_final, 1, 64, 0, stream, key, sums, scr, proof_dev);
+}
+void fin_b(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr, uint8_t* proof_dev,
+           hipStream_t stream) {
+  G16_LAUNCH(k_fin_b, 1, 64, 0, stream, key, sums, scr, proof_dev);
 }
 void fin_partial_var(ProofSums* sums, const Fr* rs_dev, hipStream_t stream) {
   G16_LAUNCH(k_fin_partial_var, 2, 64, 0, stream, sums, rs_dev);
