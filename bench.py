@@ -74,14 +74,23 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # G16_BENCH_BACKEND=gloo G16_BENCH_DEVICE=0: run the N > 1 code path with every rank on ONE GPU
+    # and the exchanges staged through the host -- a functional check of this script on a 1-GPU box,
+    # never a measurement
+    backend = os.environ.get("G16_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = int(os.environ.get("G16_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import circom_compat_amd as cc
     k = args.log2
@@ -113,8 +122,14 @@ def main():
     def exchange():
         # RCCL all-to-all over xGMI on torch's stream; only that stream is waited for, so the ctx's
         # own MSM stream keeps running underneath
-        dist.all_to_all_single(recv, send)
-        torch.cuda.current_stream().synchronize()
+        if backend == "nccl":
+            dist.all_to_all_single(recv, send)
+            torch.cuda.current_stream().synchronize()
+        else:
+            hs, hr = send.cpu(), torch.empty(nbytes, dtype=torch.uint8)
+            dist.all_to_all_single(hr, hs)
+            recv.copy_(hr)
+            torch.cuda.current_stream().synchronize()
 
     def step():
         if world == 1:
@@ -127,9 +142,13 @@ def main():
             part = prover.dist_phase3(recv.data_ptr())
         else:
             part = prover.prove_partial(rs[0], rs[1], w_dev_ptr=w_dev.data_ptr())
-        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
-        dist.all_gather_into_tensor(gathered, mine)
-        return prover.prove_finish(rs[0], rs[1], gathered.cpu().numpy().tobytes())
+        if backend == "nccl":
+            mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
+            dist.all_gather_into_tensor(gathered, mine)
+            return prover.prove_finish(rs[0], rs[1], gathered.cpu().numpy().tobytes())
+        parts = [torch.empty(1024, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, torch.frombuffer(bytearray(part), dtype=torch.uint8))
+        return prover.prove_finish(rs[0], rs[1], b"".join(p.numpy().tobytes() for p in parts))
 
     for _ in range(args.warmup):
         proof = step()
@@ -145,7 +164,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stages = prover.stage_times()
@@ -200,18 +220,20 @@ def main():
                 same = same and (cpu_proof == gpu_small.raw)
             return mats_c.num_constraints, reps, t_cpu, same
 
-        kc = min(args.cpu_log2, k)
+        # N > 1: only the byte-comparison of a small single-GPU proof (the timed baseline belongs to
+        # the N = 1 line; torchrun also pins OMP_NUM_THREADS=1)
+        kc = min(args.cpu_log2, k) if world == 1 else min(args.cpu_log2, k, 14)
         m_c, reps, t_cpu, same = cpu_case(kc, 1, 0.0)
         parity["bit_identical_to_cpu_at_2^%d" % kc] = bool(same)
         per_proof = t_cpu / reps
         grow = 0
-        while kc + grow < min(k, 22) and per_proof * (2 ** (grow + 1)) * 2 <= 20.0:
+        while world == 1 and kc + grow < min(k, 22) and per_proof * (2 ** (grow + 1)) * 2 <= 20.0:
             grow += 1
         if grow > 0:
             kc += grow
             m_c, reps, t_cpu, same = cpu_case(kc, 4, 12.0)
             parity["bit_identical_to_cpu_at_2^%d" % kc] = bool(same)
-        cpu = {"value": m_c * reps / t_cpu, "unit": "constraints/s",
+        cpu = None if world > 1 else {"value": m_c * reps / t_cpu, "unit": "constraints/s",
                "cores": cpu_ref.max_threads(), "kind": "port",
                "sample": f"{reps} proof(s) of the 2^{kc}-constraint squaring-chain circuit "
                          f"({t_cpu:.1f} s of CPU work); C restatement of ark-groth16 0.5 prove() "
