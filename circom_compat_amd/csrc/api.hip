@@ -35,6 +35,7 @@ struct g16_ctx {
   hipStream_t red = nullptr;   // G2 bucket reduction, underneath the H MSM
   hipEvent_t ev_start = nullptr, ev_ab = nullptr, ev_side = nullptr, ev_w = nullptr, ev_h = nullptr,
              ev_b2 = nullptr, ev_fixed = nullptr;
+  hipEvent_t ev_acc[3] = {nullptr, nullptr, nullptr};
   std::string err;
 
   WitnessMap wm;
@@ -131,6 +132,41 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
   static const int knob_batch = [] { const char* e = getenv("G16_BATCH_REDUCE"); return e ? atoi(e) : -1; }();
   static const int knob_b2 = [] { const char* e = getenv("G16_B2_RED_STREAM"); return e ? atoi(e) : -1; }();
   const bool small = c->cfg_w.nb() < (1u << 18);
+  const uint32_t b2_limit = c->world > 1 ? (1u << 18) : (1u << 16);
+  const bool b2_off = c->overlap && (knob_b2 < 0 ? c->cfg_w.nb() < b2_limit : knob_b2 != 0);
+  static const int knob_off = [] { const char* e = getenv("G16_REDUCE_OFF_MAIN"); return e ? atoi(e) : -1; }();
+  const bool mid = c->cfg_w.nb() >= (1u << 15) && small;
+  if ((knob_off < 0 ? mid : knob_off != 0) && c->overlap && c->work1.batch >= 3) {
+    // Mid-sized bucket sets (2^15..2^17: 2^18..2^20-constraint proofs, ranks of a sharded 2^22
+    // one): every reduction is a latency-bound chain long enough to matter and short enough to
+    // hide, so none stays on the main stream -- it only accumulates (A, B1, B2, L, then H) and the
+    // `red` stream reduces each result underneath the next accumulation.  Order: A and B1 first
+    // (the variable-base products of the finalisation need them early), B2 next (the longest
+    // reduction), L last.  Same-box A/B, ms per proof without / with: 2^17 4.21 / 4.29 (smaller
+    // sets: three reductions in a row outlast the accumulations, the batched path below wins),
+    // 2^18 5.25 / 5.06, 2^19 8.03 / 7.46, 2^20 13.46 / 12.49, 2^21 23.1 / 23.1 (larger sets: the
+    // reductions take issue slots from a saturated accumulation).
+    hipStream_t q = c->red;
+    msm_accumulate<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, s, tm);
+    msm_accumulate<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, s, tm);
+    G16_HIP(hipEventRecord(c->ev_acc[0], s));
+    G16_HIP(hipStreamWaitEvent(q, c->ev_acc[0], 0));
+    msm_reduce<Fq>(c->sort_w, c->work1, 0, 2, &S->A, q, tm);
+    after_ab(q);
+    msm_accumulate<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, 0, s, tm);
+    G16_HIP(hipEventRecord(c->ev_acc[1], s));
+    G16_HIP(hipStreamWaitEvent(q, c->ev_acc[1], 0));
+    msm_reduce<Fq2>(c->sort_w, c->work2, 0, 1, &S->B2, q, tm);
+    msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm);
+    G16_HIP(hipEventRecord(c->ev_acc[2], s));
+    G16_HIP(hipStreamWaitEvent(q, c->ev_acc[2], 0));
+    msm_reduce<Fq>(c->sort_w, c->work1, 2, 1, &S->L, q, tm);
+    after_b2();
+    G16_HIP(hipEventRecord(c->ev_b2, q));
+    G16_HIP(hipStreamWaitEvent(c->side, c->ev_b2, 0));  // the side stream joins: one event to wait on
+    G16_HIP(hipEventRecord(c->ev_side, c->side));
+    return;
+  }
   if ((knob_batch < 0 ? small : knob_batch != 0) && c->work1.batch >= 3) {
     // A, B1, L share the witness sort: three accumulations, ONE batched bucket reduction.  With
     // few buckets the reduction is pure latency (~0.4 ms of dependent EC additions whatever the
@@ -140,14 +176,14 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     msm_accumulate<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, s, tm);
     msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm);
     msm_reduce<Fq>(c->sort_w, c->work1, 0, 3, &S->A, s, tm);
-    after_ab();
+    after_ab(s);
   } else {
     // large bucket sets: the reduction is throughput bound, and reducing A and B1 at once lets
     // the variable-base part of the finalisation start ~10 ms earlier (measured at 2^22: 41.3 vs
     // 43.0 ms per proof)
     msm_run<Fq>(c->sort_w, c->ptsA, 0, c->work1, &S->A, s, tm);
     msm_run<Fq>(c->sort_w, c->ptsB1, 0, c->work1, &S->B1, s, tm);
-    after_ab();
+    after_ab(s);
     msm_run<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, &S->L, s, tm);
   }
   // B2: accumulate here; with small bucket sets its reduction (a latency-bound chain of Fq2 point
@@ -158,8 +194,7 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
   msm_accumulate<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, 0, s, tm);
   // sharded ranks: the main stream is the critical path (the witness-map phases and exchanges hide
   // under it), so the B2 reduction leaves it whenever the bucket set is small
-  const uint32_t b2_limit = c->world > 1 ? (1u << 18) : (1u << 16);
-  hipStream_t rs = (c->overlap && (knob_b2 < 0 ? c->cfg_w.nb() < b2_limit : knob_b2 != 0)) ? c->red : s;
+  hipStream_t rs = b2_off ? c->red : s;
   G16_HIP(hipEventRecord(c->ev_b2, s));
   G16_HIP(hipStreamWaitEvent(rs, c->ev_b2, 0));
   msm_reduce<Fq2>(c->sort_w, c->work2, 0, 1, &S->B2, rs, tm);
@@ -277,6 +312,7 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     G16_HIP(hipEventCreateWithFlags(&c->ev_ab, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_b2, hipEventDisableTiming));
+    for (auto& e : c->ev_acc) G16_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_fixed, hipEventDisableTiming));
     hipStream_t s = c->stream;
     c->N = key->n_vars;
@@ -417,6 +453,8 @@ void g16_ctx_destroy(g16_ctx* c) {
   if (c->ev_ab) (void)hipEventDestroy(c->ev_ab);
   if (c->ev_side) (void)hipEventDestroy(c->ev_side);
   if (c->ev_b2) (void)hipEventDestroy(c->ev_b2);
+  for (auto e : c->ev_acc)
+    if (e) (void)hipEventDestroy(e);
   if (c->ev_fixed) (void)hipEventDestroy(c->ev_fixed);
   delete c;
 }
@@ -510,9 +548,9 @@ g16_status g16_prove_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], 
     G16_HIP(hipEventRecord(c->ev_fixed, c->side));
     run_msms(
         c, (const Fr*)w_dev,
-        [&] {
+        [&](hipStream_t from) {
           // A and B1 are enqueued: g_a, g1_b and the two variable-base products overlap L / B2 / H
-          G16_HIP(hipEventRecord(c->ev_ab, s));
+          G16_HIP(hipEventRecord(c->ev_ab, from));
           G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
           fin_var(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->fin_scr.p, c->out_dev.p, c->side);
         },
@@ -554,9 +592,9 @@ g16_status g16_prove_partial_dev(g16_ctx* c, const uint64_t r[4], const uint64_t
   return guarded(c, [&]() -> g16_status {
     hipStream_t s = c->stream;
     begin_sharded(c, r, s_);
-    run_msms(c, (const Fr*)w_dev, [&] {
+    run_msms(c, (const Fr*)w_dev, [&](hipStream_t from) {
       // this rank's s*A and r*B1 (variable-base, one wave each) overlap its L / B2 / H MSMs
-      G16_HIP(hipEventRecord(c->ev_ab, s));
+      G16_HIP(hipEventRecord(c->ev_ab, from));
       G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
       fin_partial_var(c->sums_dev.p, c->rs_dev.p, c->side);
     });
@@ -628,8 +666,8 @@ g16_status g16_prove_dist_phase1(g16_ctx* c, const uint64_t r[4], const uint64_t
     c->wd.phase1((const Fr*)w_dev, (int32_t*)send_dev, x);
     // the witness-scalar MSMs of this rank's point range run on the main stream during both
     // exchanges and phases 2-3
-    enqueue_witness_msms(c, (const Fr*)w_dev, [&] {
-      G16_HIP(hipEventRecord(c->ev_ab, s));
+    enqueue_witness_msms(c, (const Fr*)w_dev, [&](hipStream_t from) {
+      G16_HIP(hipEventRecord(c->ev_ab, from));
       G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
       fin_partial_var(c->sums_dev.p, c->rs_dev.p, c->side);
     }, [] {});

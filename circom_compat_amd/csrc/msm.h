@@ -20,6 +20,7 @@
 //    0/1) neither serialise on a hot bucket nor leave lanes idle; a hot bucket simply spans many
 //    lanes and its partials are tree-summed by a workgroup.
 #pragma once
+#include <stdlib.h>
 #include "common.h"
 #include "ec29.h"
 
@@ -29,7 +30,7 @@ constexpr int MSM_ACC_THREADS = 128;    // workgroup of the accumulation kernel
 constexpr int MSM_ACC_BLOCKS = 2048;    // persistent grid: 4 waves per SIMD on 256 CUs (G16_ACC_GRID overrides)
 constexpr int MSM_MIN_SEG = 8;          // shortest per-lane segment
 constexpr int MSM_SMALL_MULTI = 32;     // buckets with <= this many partials are summed inside the reduce
-constexpr int MSM_RED_CHUNK = 8;    // max buckets per thread in the weighted bucket reduction
+constexpr int MSM_RED_CHUNK = 16;   // max buckets per thread in the weighted bucket reduction
 constexpr uint32_t MSM_IDX_BITS = 26;
 constexpr uint32_t MSM_IDX_MASK = (1u << MSM_IDX_BITS) - 1u;
 
@@ -43,11 +44,22 @@ struct MsmConfig {
   uint32_t nb() const { return (uint32_t)D * B; }
 };
 
-// buckets per thread of k_bucket_reduce: as many threads as ~2 waves per SIMD, at most MSM_RED_CHUNK
-inline uint32_t msm_red_chunk(const MsmConfig& cfg) {
-  uint32_t ch = (uint32_t)(((uint64_t)cfg.D * cfg.B) / 131072u);
+// buckets per thread of k_bucket_reduce.  The kernel is a serial chain of ~3 EC additions per bucket
+// plus one lo * run product (~21 addition-equivalents) per thread, each addition ~9 us of one wave's
+// issue slots: one wave per SIMD (65536 threads) minimises chain x waves-per-SIMD.  Measured at
+// 2^22 (2^19 buckets): 8 per thread 5.0 ms of reductions per proof vs 6.35 ms at 4, 8.7 ms at 2.
+inline uint32_t msm_red_chunk(const MsmConfig& cfg, uint32_t nbatch = 1) {
+  static const uint32_t lanes_target = [] {
+    const char* e = getenv("G16_RED_LANES");  // tuning knob: threads the reduction aims for
+    return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 65536u;
+  }();
+  uint32_t ch = (uint32_t)(((uint64_t)nbatch * cfg.D * cfg.B) / lanes_target);
   if (ch < 1) ch = 1;
-  if (ch > (uint32_t)MSM_RED_CHUNK) ch = MSM_RED_CHUNK;
+  static const uint32_t ch_max = [] {
+    const char* e = getenv("G16_RED_MAX");
+    return e && atoi(e) > 0 ? (uint32_t)atoi(e) : (uint32_t)MSM_RED_CHUNK;
+  }();
+  if (ch > ch_max) ch = ch_max;
   return ch;
 }
 

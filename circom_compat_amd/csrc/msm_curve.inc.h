@@ -253,10 +253,16 @@ __global__ void __launch_bounds__(64)
     acc.add(run);
   }
   if (lo != 0 && !run.is_inf()) {
+    // lo * run, signed binary (NAF) double-and-add: digit i of lo is +1 / -1 where bit i+1 of
+    // (3 lo) & ~lo / lo & ~(3 lo) is set; one addition per three doublings on average
+    const uint64_t h3 = 3ull * lo;
+    const uint64_t pos = (h3 & ~(uint64_t)lo) >> 1, neg = ((uint64_t)lo & ~h3) >> 1;
+    const MsmAcc<F> run_neg = run.neg();
     MsmAcc<F> m = MsmAcc<F>::infinity();
-    for (int bit = 31 - __clz(lo); bit >= 0; --bit) {
+    for (int bit = 63 - __clzll((unsigned long long)pos); bit >= 0; --bit) {
       m.dbl_in_place();
-      if ((lo >> bit) & 1) m.add(run);
+      if ((pos >> bit) & 1) m.add(run);
+      else if ((neg >> bit) & 1) m.add(run_neg);
     }
     acc.add(m);
   }
@@ -370,7 +376,7 @@ void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, 
              (const uint32_t*)s.offset.p, nb, cfg.lanes, partial, (size_t)work.slots);
   // buckets per thread: the running sums are a dependent chain of EC additions (~10 us each on
   // one lane), so small bucket sets are latency bound: keep >= ~2 waves per SIMD busy
-  const uint32_t red_chunk = msm_red_chunk(cfg);
+  const uint32_t red_chunk = msm_red_chunk(cfg, (uint32_t)nbatch);
   const uint32_t cps = ceil_div(cfg.B, red_chunk);
   const uint32_t nchunks = cps * (uint32_t)cfg.D;
   if (nchunks > work.ncontrib) throw std::runtime_error("msm_reduce: contribution buffer too small");
