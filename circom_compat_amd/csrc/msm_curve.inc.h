@@ -244,26 +244,67 @@ __global__ void __launch_bounds__(64)
   const uint32_t lo = (q % chunks_per_set) * red_chunk;
   uint32_t hi = lo + red_chunk;
   if (hi > B) hi = B;
+  // Running sums over the thread's buckets, highest first: run += every partial of the bucket, then
+  // acc += run.  Flattened so that every iteration of every lane is exactly ONE addition (buckets
+  // own 1..3 partials: a per-bucket inner loop would run each wave at the maximum over its lanes).
   MsmAcc<F> run = MsmAcc<F>::infinity(), acc = MsmAcc<F>::infinity();
-  for (uint32_t b = hi; b-- > lo;) {
-    uint32_t first, nt;
-    bucket_slots(offset, set * B + b, S, &first, &nt);
-    if (nt > (uint32_t)MSM_SMALL_MULTI) nt = 1;  // pre-summed into the first slot by k_combine_large
-    for (uint32_t k = 0; k < nt; ++k) run.add(partial[first + k]);
-    acc.add(run);
+  uint32_t b = hi, first = 0, left = 0;
+  bool pending = false;  // the acc += run of bucket b is still to do
+  for (;;) {
+    if (left == 0 && !pending) {
+      if (b == lo) break;
+      --b;
+      bucket_slots(offset, set * B + b, S, &first, &left);
+      if (left > (uint32_t)MSM_SMALL_MULTI) left = 1;  // pre-summed into the first slot by k_combine_large
+      pending = true;
+    }
+    const bool is_slot = left > 0;
+    MsmAcc<F> x = is_slot ? run : acc, y = run;
+    if (is_slot) y = partial[first + --left];
+    x.add(y);  // the one addition of this iteration, operands selected
+    if (is_slot) {
+      run = x;
+    } else {
+      acc = x;
+      pending = false;
+    }
   }
   if (lo != 0 && !run.is_inf()) {
-    // lo * run, signed binary (NAF) double-and-add: digit i of lo is +1 / -1 where bit i+1 of
-    // (3 lo) & ~lo / lo & ~(3 lo) is set; one addition per three doublings on average
-    const uint64_t h3 = 3ull * lo;
-    const uint64_t pos = (h3 & ~(uint64_t)lo) >> 1, neg = ((uint64_t)lo & ~h3) >> 1;
-    const MsmAcc<F> run_neg = run.neg();
-    MsmAcc<F> m = MsmAcc<F>::infinity();
-    for (int bit = 63 - __clzll((unsigned long long)pos); bit >= 0; --bit) {
-      m.dbl_in_place();
-      if ((pos >> bit) & 1) m.add(run);
-      else if ((neg >> bit) & 1) m.add(run_neg);
+    // acc += lo * run, radix-4 signed digits {-1, 0, 1, 2} of lo, most significant first: the same
+    // trip count (nd, from the largest offset of the grid) and the same 2 doublings + 1 addition
+    // per digit in every lane of the wave (a binary or NAF ladder adds whenever ANY lane's bit is
+    // set, i.e. always)
+    uint64_t digits = 0;  // 3 bits per digit: value + 1
+    uint32_t v = lo;
+    int nd = 0;
+    for (uint32_t m = (chunks_per_set - 1) * red_chunk; m != 0 || nd == 0; m >>= 2) ++nd;
+    ++nd;  // room for the last carry
+    for (int d = 0; d < nd; ++d) {
+      uint32_t t = v & 3u;
+      v >>= 2;
+      if (t == 3u) {
+        ++v;  // 3 = 4 - 1
+        t = 0u;  // encodes -1
+      } else {
+        ++t;
+      }
+      digits |= (uint64_t)t << (3 * d);
     }
+    contrib[q] = acc;  // parked in its destination: one point less to keep in registers (Fq2)
+    MsmAcc<F> run2 = run;
+    run2.dbl_in_place();
+    MsmAcc<F> m = MsmAcc<F>::infinity();
+    for (int d = nd - 1; d >= 0; --d) {
+      m.dbl_in_place();
+      m.dbl_in_place();
+      const uint32_t t = (uint32_t)(digits >> (3 * d)) & 7u;  // digit + 1
+      if (t != 1u) {
+        MsmAcc<F> y = t == 3u ? run2 : run;
+        if (t == 0u) y = y.neg();
+        m.add(y);
+      }
+    }
+    acc = contrib[q];
     acc.add(m);
   }
   contrib[q] = acc;
