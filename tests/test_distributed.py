@@ -24,12 +24,17 @@ WORKER = textwrap.dedent('''
     lib = _binding.Library(os.path.join(ROOT, "tests", "emu", "libg16_emu.so"))
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cons, w, n_vars, n_pub = H.squaring_chain(int(sys.argv[2]))
+    if sys.argv[3] == "dense":   # uneven rows, skewed witness, several public inputs
+        cons, w, n_vars, _ = H.dense_skewed_circuit((1 << int(sys.argv[2])) - 5, seed=3, long_rows=(7,))
+        n_pub = 3
+    else:
+        cons, w, n_vars, n_pub = H.squaring_chain(int(sys.argv[2]))
+    ni = n_pub + 1
     rng = random.Random(42)
     tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
     opk = o.trapdoor_setup(cons, n_vars, n_pub, *tox)
     a_rows, b_rows = o.matrices_from_r1cs(cons)
-    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, lib)
+    mats = H.matrices_from_rows(a_rows, b_rows, ni, n_vars, lib)
     pk = H.pk_from_oracle(opk)
     r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
     pr = cc.Prover(pk, mats, lib=lib, rank=rank, world=world)
@@ -38,7 +43,7 @@ WORKER = textwrap.dedent('''
     gathered = torch.empty(world * 1024, dtype=torch.uint8)
     dist.all_gather_into_tensor(gathered, mine)
     proof = pr.prove_finish(r, s, gathered.numpy().tobytes())
-    want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2, len(cons), w)
+    want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), ni, len(cons), w)
     assert proof.raw == o.proof_to_bytes(want), "sharded proof differs from the oracle"
     # fully sharded: the witness map is distributed too (four-step NTTs, two all-to-all exchanges)
     pd = cc.Prover(pk, mats, lib=lib, rank=rank, world=world, dist_wm=True)
@@ -55,7 +60,7 @@ WORKER = textwrap.dedent('''
     dist.all_gather_into_tensor(g2, torch.frombuffer(bytearray(part2), dtype=torch.uint8))
     proof2 = pd.prove_finish(r, s, g2.numpy().tobytes())
     assert proof2.raw == o.proof_to_bytes(want), "fully sharded proof differs from the oracle"
-    assert o.verify_proof(opk, w[1:2], H.proof_from_bytes(proof.raw))
+    assert o.verify_proof(opk, w[1:ni], H.proof_from_bytes(proof.raw))
     # every rank must have produced the identical proof
     t = torch.frombuffer(bytearray(proof.raw), dtype=torch.uint8).clone()
     ref = t.clone()
@@ -67,8 +72,8 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("world,logm", [(2, 4), (4, 6)])
-def test_sharded_prove_gloo(emu, tmp_path, world, logm):
+@pytest.mark.parametrize("world,logm,kind", [(2, 4, "chain"), (4, 6, "chain"), (2, 5, "dense")])
+def test_sharded_prove_gloo(emu, tmp_path, world, logm, kind):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     import socket
@@ -77,7 +82,7 @@ def test_sharded_prove_gloo(emu, tmp_path, world, logm):
         port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script), ROOT, str(logm)]
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script), ROOT, str(logm), kind]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     for k in range(world):

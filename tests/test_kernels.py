@@ -279,6 +279,40 @@ def test_dense_skewed_circuit_through_zkey_writer_and_loader(lib, tmp_path):
     assert proof.raw == o.proof_to_bytes(want)
 
 
+@pytest.mark.parametrize("n_pub", [4, 7])
+def test_several_public_inputs(lib, tmp_path, n_pub):
+    """num_inputs = p + 1 > 2 (every reference fixture has p = 1): the witness map copies p + 1
+    witness rows after the constraints (qap.rs:46-48), the L query starts at wire p + 1
+    (src/zkey.rs:118-121), the verifier folds p inputs into IC.  Wires 1..p of the dense circuit are
+    declared public; key through the zkey writer and loader; proof bytes equal the oracle's and the
+    proof verifies against exactly those p inputs."""
+    import circom_compat_amd as cc
+    cons, w, n_vars, _ = H.dense_skewed_circuit(45, seed=11 + n_pub, long_rows=(9,))
+    ni = n_pub + 1
+    rows = lambda k: [[(c, wdx) for wdx, c in con[k]] for con in cons]
+    a, b, c = (cc.Csr.from_rows(rows(k), lib) for k in range(3))
+    rng = random.Random(21 + n_pub)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    pk = cc.trapdoor_setup(a, b, c, n_vars, n_pub, tox, lib=lib)
+    assert len(pk.vk.gamma_abc_g1) == ni and pk.l_query.shape[0] == n_vars - ni
+    mats = cc.ConstraintMatrices(ni, n_vars - n_pub, len(cons), a, b)
+    path = str(tmp_path / "pub.zkey")
+    cc.write_zkey(path, pk, mats, lib=lib)
+    pk2, mats2 = cc.read_zkey(path, lib)
+    assert pk2.n_public == n_pub and mats2.num_instance_variables == ni
+    opk, omats = o.read_zkey(open(path, "rb").read())
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    want = o.create_proof_with_reduction_and_matrices(opk, r, s, omats, ni, len(cons), w)
+    assert o.verify_proof(opk, w[1:ni], want)
+    bad = list(w[1:ni])
+    bad[-1] = (bad[-1] + 1) % o.R_MOD
+    assert not o.verify_proof(opk, bad, want)
+    proof = cc.Groth16.create_proof_with_reduction_and_matrices(pk2, r, s, mats2, ni, len(cons), w, lib=lib)
+    assert proof.raw == o.proof_to_bytes(want)
+    h = cc.CircomReduction.witness_map_from_matrices(mats2, ni, len(cons), w, lib=lib)
+    assert cc.fr_to_ints(h) == o.witness_map_from_matrices(omats["a"], omats["b"], ni, len(cons), w)
+
+
 # ---- LibsnarkReduction (arkworks-generated keys): reference tests/groth16.rs ---------------------
 def _fixture(golden, name):
     import json
