@@ -27,7 +27,7 @@
 namespace g16 {
 
 constexpr int MSM_ACC_THREADS = 128;    // workgroup of the accumulation kernel
-constexpr int MSM_ACC_BLOCKS = 2048;    // persistent grid: 4 waves per SIMD on 256 CUs (G16_ACC_GRID overrides)
+constexpr int MSM_ACC_BLOCKS = 2048;    // segments = 2048 x 128: two rounds of 2 waves per SIMD on 256 CUs (G16_ACC_GRID overrides)
 constexpr int MSM_MIN_SEG = 8;          // shortest per-lane segment
 constexpr int MSM_SMALL_MULTI = 32;     // buckets with <= this many partials are summed inside the reduce
 constexpr int MSM_RED_CHUNK = 16;   // max buckets per thread in the weighted bucket reduction

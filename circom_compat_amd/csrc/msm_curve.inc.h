@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offse
   return lo;
 }
 
-// per-way state of the accumulation kernel (plain struct of scalars + registers: no arrays, no
+// per-segment state of the accumulation kernel (plain struct of scalars + registers: no arrays, no
 // address-taken locals, so everything stays in VGPRs)
 template <class F>
 struct AccWay {
@@ -133,43 +133,33 @@ __device__ __forceinline__ void acc_way_commit(AccWay<F>& w, bool step,
   if (step) ++w.pos;
 }
 
-// One lane = one (G2) or two (G1) equal segments of the sorted entry list.  With two ways the
-// mixed additions of both segments sit in one basic block, so the scheduler interleaves their
-// dependent multiply-add chains (a single chain cannot keep the half-rate multiplier busy: ~11
-// cycles of latency per ~4-cycle issue); a G2 addition already carries that much independent work
-// in its Fq2 products.
+// One lane = one equal segment of the sorted entry list (persistent grid: `lanes` segments over
+// gridDim.x * blockDim.x threads, normally one each).  The dependent multiply-add chains of one
+// mixed addition cannot keep the half-rate multiplier busy on their own (~11 cycles of latency per
+// ~8-cycle issue); the two waves per SIMD its 229 VGPRs allow do (the grid of 2048 x 128 threads
+// runs as two rounds of resident workgroups; 1024 and 4096 workgroups measured slower).  Interleaving
+// two segments per lane in one basic block was measured and lost: ~450 VGPRs (1 wave per SIMD),
+// 21.4 vs 17.5 ms for the four G1 MSMs of a 2^22 proof; capped at 256 VGPRs it spills.
 template <class F>
 __global__ void __launch_bounds__(ACC_THREADS)
     k_bucket_accumulate(const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min,
                         const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset,
                         uint32_t nb, uint32_t lanes, MsmAcc<F>* __restrict__ partial) {
   using LF = typename Lazy<F>::type;
-  // measured on MI355X: two ways need ~450 VGPRs (1 wave per SIMD) and lose to one way at 3 waves
-  // per SIMD (21.4 vs 17.5 ms for the four G1 MSMs of a 2^22 proof); capped at 256 VGPRs they spill
-  constexpr bool TWO = false;
   const uint32_t M = offset[nb];
   const uint32_t S = msm_seg_len(M, lanes);
   const uint32_t nthreads = gridDim.x * blockDim.x;
-  const uint32_t way_stride = TWO ? lanes / 2 : lanes;  // way 1 of thread t owns segment t + lanes/2
-  for (uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x; t0 < way_stride; t0 += nthreads) {
-    AccWay<F> w0, w1;
-    acc_way_init<F>(w0, t0, S, M, pts, npts, idx_min, entries, offset, nb);
-    if (TWO) acc_way_init<F>(w1, t0 + way_stride, S, M, pts, npts, idx_min, entries, offset, nb);
-    if (!w0.live) break;  // segments are handed out in order: nothing left for later threads either
+  for (uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x; t0 < lanes; t0 += nthreads) {
+    AccWay<F> w;
+    acc_way_init<F>(w, t0, S, M, pts, npts, idx_min, entries, offset, nb);
+    if (!w.live) break;  // segments are handed out in order: nothing left for later threads either
     for (uint32_t it = 0; it < S; ++it) {
-      bool step0, step1 = false, sp0, sp1 = false;
-      Aff29<LF> p0 = acc_way_prepare<F>(w0, &step0, pts, npts, idx_min, entries, offset, partial);
-      Aff29<LF> p1;
-      if (TWO) p1 = acc_way_prepare<F>(w1, &step1, pts, npts, idx_min, entries, offset, partial);
-      // the arithmetic of both ways in one straight-line block
-      XYZZ29<LF> r0 = XYZZ29<LF>::madd_select(w0.acc, p0, &sp0);
-      XYZZ29<LF> r1;
-      if (TWO) r1 = XYZZ29<LF>::madd_select(w1.acc, p1, &sp1);
-      acc_way_commit<F>(w0, step0, r0, sp0, p0);
-      if (TWO) acc_way_commit<F>(w1, step1, r1, sp1, p1);
+      bool step, special;
+      const Aff29<LF> p = acc_way_prepare<F>(w, &step, pts, npts, idx_min, entries, offset, partial);
+      const XYZZ29<LF> r = XYZZ29<LF>::madd_select(w.acc, p, &special);
+      acc_way_commit<F>(w, step, r, special, p);
     }
-    partial[w0.g + w0.seg] = w0.acc;
-    if (TWO && w1.live) partial[w1.g + w1.seg] = w1.acc;
+    partial[w.g + w.seg] = w.acc;
   }
 }
 
@@ -416,7 +406,7 @@ void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, 
              stream, (const uint32_t*)s.multi_l.p, (const uint32_t*)s.meta.p,
              (const uint32_t*)s.offset.p, nb, cfg.lanes, partial, (size_t)work.slots);
   // buckets per thread: the running sums are a dependent chain of EC additions (~10 us each on
-  // one lane), so small bucket sets are latency bound: keep >= ~2 waves per SIMD busy
+  // one lane): see msm_red_chunk for the thread count this aims at
   const uint32_t red_chunk = msm_red_chunk(cfg, (uint32_t)nbatch);
   const uint32_t cps = ceil_div(cfg.B, red_chunk);
   const uint32_t nchunks = cps * (uint32_t)cfg.D;
