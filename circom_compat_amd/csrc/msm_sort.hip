@@ -12,13 +12,17 @@ namespace g16 {
 MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
   MsmConfig cfg;
   // window size from a cost model: len * W(c) mixed additions in the bucket kernel plus ~8
-  // mixed-addition equivalents per bucket in the reduction (measured at n = 2^22: c = 20 beats 19,
-  // 21 and 22; profiles/r01_window_sweep.txt)
+  // mixed-addition equivalents per bucket in the reduction.  Windows whose TOP digit has few
+  // significant bits (254 - c (W - 1) <= 9: c = 18, 19, 21) are skipped for large inputs: all len
+  // top digits land in <= 512 buckets, each spanning more than MSM_SMALL_MULTI lane segments (hot
+  // LDS-atomic bins in the sort, a k_combine_large tree per bucket).  Measured sweeps:
+  // profiles/r01_window_sweep.txt.
   int c = 3;
   double best = 1e300;
   for (int t = 3; t <= 22; ++t) {
-    const double Wt = (double)((255 + t - 1) / t);
-    const double cost = (double)len * Wt + 8.0 * (double)((size_t)1 << (t - 1));
+    const int Wt = (255 + t - 1) / t;
+    if (len >= ((size_t)1 << 18) && 254 - t * (Wt - 1) <= 9) continue;
+    const double cost = (double)len * (double)Wt + 8.0 * (double)((size_t)1 << (t - 1));
     if (cost < best) {
       best = cost;
       c = t;
