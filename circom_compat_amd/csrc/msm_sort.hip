@@ -49,24 +49,29 @@ MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
 namespace {
 
 
+// bits [bit, bit + c) of a 256-bit scalar (c <= 24).  Selected with compares over the eight words
+// instead of indexing them: a runtime index would move the scalar to scratch memory, i.e. one or
+// two ~1 us memory round trips per digit.
+__device__ __forceinline__ uint32_t window_bits(const U256& sc, int bit, int c) {
+  const int limb = bit >> 5, sh = bit & 31;
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k == limb) lo = sc.v[k];
+    if (k == limb + 1) hi = sc.v[k];
+  }
+  const uint64_t two = ((uint64_t)hi << 32) | lo;
+  return (uint32_t)(two >> sh) & ((1u << c) - 1u);
+}
+
 // Walks the signed c-bit digits of canonical scalar i; emit(g, entry) for every non-zero digit.
 template <class Emit>
 __device__ __forceinline__ void for_each_digit(const U256& scalar, uint32_t i, int c, int W, int D,
                                                uint32_t B, Emit emit) {
-  const uint32_t* sp = scalar.v;
-  const uint32_t mask = (1u << c) - 1u;
   const uint32_t half = 1u << (c - 1);
   uint32_t carry = 0;
   for (int w = 0; w < W; ++w) {
-    const int bit = w * c;
-    const int limb = bit >> 5, sh = bit & 31;
-    uint32_t raw = 0;
-    if (limb < 8) {
-      raw = sp[limb] >> sh;
-      if (sh + c > 32 && limb + 1 < 8) raw |= sp[limb + 1] << (32 - sh);
-      raw &= mask;
-    }
-    raw += carry;
+    uint32_t raw = window_bits(scalar, w * c, c) + carry;
     uint32_t mag, neg;
     if (raw > half) {
       mag = (1u << c) - raw;
@@ -83,6 +88,34 @@ __device__ __forceinline__ void for_each_digit(const U256& scalar, uint32_t i, i
     }
   }
 }
+
+// The same walk one window at a time (state = the carry), so that several scalars can advance in
+// lock step and their LDS ranks / stores overlap.
+struct DigitWalker {
+  U256 sc;
+  uint32_t carry = 0;
+  // window w of scalar i: returns false for a zero digit
+  __device__ __forceinline__ bool next(int w, uint32_t i, int c, int D, uint32_t B, uint32_t* g,
+                                       uint32_t* entry) {
+    const uint32_t half = 1u << (c - 1);
+    const uint32_t raw = window_bits(sc, w * c, c) + carry;
+    uint32_t mag, neg;
+    if (raw > half) {
+      mag = (1u << c) - raw;
+      neg = 1;
+      carry = 1;
+    } else {
+      mag = raw;
+      neg = 0;
+      carry = 0;
+    }
+    if (!mag) return false;
+    const uint32_t d = (uint32_t)(w % D), j = (uint32_t)(w / D);
+    *g = d * B + (mag - 1);
+    *entry = i | (j << MSM_IDX_BITS) | (neg << 31);
+    return true;
+  }
+};
 
 // ---- two-level counting sort of the (bucket, entry) pairs ---------------------------------------
 // A single-level sort needs one global atomic per entry and per pass (2 x 58.7 M at n = 2^22:
@@ -154,14 +187,32 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
       h[b] = cnt ? atomicAdd(&cursor1[b], cnt) : 0u;
     }
     __syncthreads();
-    for (int k = 0; k < P1_PER_THREAD; ++k) {
-      const uint32_t i = tile * P1_TILE + k * P1_THREADS + tid;
-      if (i >= n) continue;
-      const U256 sc = load_scalar<MONT>(scalars, i);
-      for_each_digit(sc, i, G.c, G.W, G.D, G.B, [&](uint32_t g, uint32_t e) {
-        const uint32_t pos = atomicAdd(&h[g >> G.sh], 1u);
-        part[pos] = MsmPair{e, g};
-      });
+    // four scalars advance window by window together: their four LDS ranks are issued back to
+    // back, then the four stores (one scalar at a time the rank -> store chain is pure latency)
+    constexpr int U = 4;
+    static_assert(P1_PER_THREAD % U == 0, "P1_PER_THREAD must be a multiple of the unroll");
+    for (int k0 = 0; k0 < P1_PER_THREAD; k0 += U) {
+      DigitWalker wk[U];
+      uint32_t idx[U];
+      bool live[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        idx[u] = tile * P1_TILE + (k0 + u) * P1_THREADS + tid;
+        live[u] = idx[u] < n;
+        if (live[u]) wk[u].sc = load_scalar<MONT>(scalars, idx[u]);
+      }
+      for (int w = 0; w < G.W; ++w) {
+        uint32_t g[U], e[U], pos[U];
+        bool v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          v[u] = live[u] && wk[u].next(w, idx[u], G.c, G.D, G.B, &g[u], &e[u]);
+          if (v[u]) pos[u] = atomicAdd(&h[g[u] >> G.sh], 1u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (v[u]) part[pos[u]] = MsmPair{e[u], g[u]};
+      }
     }
     __syncthreads();
   }
@@ -217,9 +268,21 @@ __global__ void __launch_bounds__(P2_THREADS) k_bucket_scatter(const MsmPair* pa
         h[b] = cnt ? atomicAdd(&cursor[gmin + b], cnt) : 0u;
       }
       __syncthreads();
-      for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) {
-        const MsmPair pe = part[j];
-        entries[atomicAdd(&h[pe.y - gmin], 1u)] = pe.x;
+      // four pairs in flight per thread: the loads are issued before the LDS ranks that depend on them
+      for (uint32_t j0 = lo + tid; j0 < hi; j0 += 4 * P2_THREADS) {
+        MsmPair pe[4];
+        uint32_t pos[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t j = j0 + u * P2_THREADS;
+          pe[u] = j < hi ? part[j] : MsmPair{0u, 0xffffffffu};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (pe[u].y != 0xffffffffu) pos[u] = atomicAdd(&h[pe[u].y - gmin], 1u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (pe[u].y != 0xffffffffu) entries[pos[u]] = pe[u].x;
       }
       __syncthreads();
     } else {
