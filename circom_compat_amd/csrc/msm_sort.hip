@@ -234,7 +234,17 @@ __global__ void __launch_bounds__(P2_THREADS) k_bucket_count(const MsmPair* part
     if (range <= (uint32_t)P2_BINS) {
       for (uint32_t b = tid; b < range; b += P2_THREADS) h[b] = 0;
       __syncthreads();
-      for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) atomicAdd(&h[part[j].y - gmin], 1u);
+      for (uint32_t j0 = lo + tid; j0 < hi; j0 += 8 * P2_THREADS) {  // eight loads in flight
+        uint32_t y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t j = j0 + (uint32_t)u * P2_THREADS;
+          y[u] = j < hi ? part[j].y : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (y[u] != 0xffffffffu) atomicAdd(&h[y[u] - gmin], 1u);
+      }
       __syncthreads();
       for (uint32_t b = tid; b < range; b += P2_THREADS)
         if (h[b]) atomicAdd(&count[gmin + b], h[b]);
@@ -245,47 +255,54 @@ __global__ void __launch_bounds__(P2_THREADS) k_bucket_count(const MsmPair* part
   }
 }
 
-// level 2, pass B: final placement
+// level 2, pass B: final placement.  A chunk's pairs are loaded ONCE into registers (P2S_PER per
+// thread, all loads in flight together), counted into the LDS histogram, and scattered from the
+// registers after the chunk's runs have been reserved.
+constexpr int P2S_PER = 32, P2S_CHUNK = P2_THREADS * P2S_PER, P2S_GROUP = 8;
 __global__ void __launch_bounds__(P2_THREADS) k_bucket_scatter(const MsmPair* part,
                                                                const uint32_t* total_ptr, int sh,
                                                                uint32_t* cursor, uint32_t* entries) {
   __shared__ uint32_t h[P2_BINS];
   const int tid = threadIdx.x;
   const uint32_t total = *total_ptr;
-  const uint32_t nchunks = (total + P2_CHUNK - 1) / P2_CHUNK;
+  const uint32_t nchunks = (total + P2S_CHUNK - 1) / P2S_CHUNK;
+  constexpr uint32_t NONE = 0xffffffffu;  // never a bucket id
   for (uint32_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-    const uint32_t lo = ch * P2_CHUNK;
-    const uint32_t hi = lo + P2_CHUNK < total ? lo + P2_CHUNK : total;
+    const uint32_t lo = ch * P2S_CHUNK;
+    const uint32_t hi = lo + P2S_CHUNK < total ? lo + P2S_CHUNK : total;
     const uint32_t gmin = (part[lo].y >> sh) << sh;
     const uint32_t range = (((part[hi - 1].y >> sh) + 1u) << sh) - gmin;
     if (range <= (uint32_t)P2_BINS) {
       for (uint32_t b = tid; b < range; b += P2_THREADS) h[b] = 0;
+      MsmPair pe[P2S_PER];
+#pragma unroll
+      for (int u = 0; u < P2S_PER; ++u) {
+        const uint32_t j = lo + (uint32_t)u * P2_THREADS + tid;
+        pe[u] = j < hi ? part[j] : MsmPair{0u, NONE};
+      }
       __syncthreads();
-      for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) atomicAdd(&h[part[j].y - gmin], 1u);
+#pragma unroll
+      for (int u = 0; u < P2S_PER; ++u)
+        if (pe[u].y != NONE) atomicAdd(&h[pe[u].y - gmin], 1u);
       __syncthreads();
+      // reserve this chunk's run in every bucket; h[] becomes the running write cursor
       for (uint32_t b = tid; b < range; b += P2_THREADS) {
         const uint32_t cnt = h[b];
         h[b] = cnt ? atomicAdd(&cursor[gmin + b], cnt) : 0u;
       }
       __syncthreads();
-      // four pairs in flight per thread: the loads are issued before the LDS ranks that depend on them
-      for (uint32_t j0 = lo + tid; j0 < hi; j0 += 4 * P2_THREADS) {
-        MsmPair pe[4];
-        uint32_t pos[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t j = j0 + u * P2_THREADS;
-          pe[u] = j < hi ? part[j] : MsmPair{0u, 0xffffffffu};
-        }
+      for (int u0 = 0; u0 < P2S_PER; u0 += P2S_GROUP) {  // ranks of a group back to back, then its stores
+        uint32_t pos[P2S_GROUP];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (pe[u].y != 0xffffffffu) pos[u] = atomicAdd(&h[pe[u].y - gmin], 1u);
+        for (int u = 0; u < P2S_GROUP; ++u)
+          if (pe[u0 + u].y != NONE) pos[u] = atomicAdd(&h[pe[u0 + u].y - gmin], 1u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (pe[u].y != 0xffffffffu) entries[pos[u]] = pe[u].x;
+        for (int u = 0; u < P2S_GROUP; ++u)
+          if (pe[u0 + u].y != NONE) entries[pos[u]] = pe[u0 + u].x;
       }
       __syncthreads();
-    } else {
+    } else {  // sparse buckets (tiny inputs or huge windows): plain global atomics
       for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) {
         const MsmPair pe = part[j];
         entries[atomicAdd(&cursor[pe.y], 1u)] = pe.x;
@@ -455,7 +472,10 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
   const uint32_t* total = part_off.p + G.bins1;
   G16_LAUNCH(k_bucket_count, grid2, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, count.p);
   scan_exclusive(count.p, nb, 0, offset.p, cursor.p, scan_tmp.p, s);
-  G16_LAUNCH(k_bucket_scatter, grid2, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, cursor.p,
+  uint32_t grid3 = ceil_div((uint64_t)n * cfg.W, P2S_CHUNK);
+  if (grid3 > 2 * grid_cap) grid3 = 2 * grid_cap;
+  if (grid3 < 1) grid3 = 1;
+  G16_LAUNCH(k_bucket_scatter, grid3, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, cursor.p,
              entries.p);
   G16_LAUNCH(k_find_large, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)offset.p, nb, cfg.lanes,
              multi_l.p, meta.p);
