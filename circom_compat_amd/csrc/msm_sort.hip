@@ -173,13 +173,23 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
   const uint32_t ntiles = (n + P1_TILE - 1) / P1_TILE;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     for (uint32_t b = tid; b < G.bins1; b += P1_THREADS) h[b] = 0;
-    __syncthreads();
+    // the tile's scalars are read (and brought to canonical form) once and stay in registers for
+    // both passes: the tile histogram and the scatter
+    U256 sc[P1_PER_THREAD];
+    uint32_t idx[P1_PER_THREAD];
+    bool live[P1_PER_THREAD];
+#pragma unroll
     for (int k = 0; k < P1_PER_THREAD; ++k) {
-      const uint32_t i = tile * P1_TILE + k * P1_THREADS + tid;
-      if (i >= n) continue;
-      const U256 sc = load_scalar<MONT>(scalars, i);
-      for_each_digit(sc, i, G.c, G.W, G.D, G.B, [&](uint32_t g, uint32_t) { atomicAdd(&h[g >> G.sh], 1u); });
+      idx[k] = tile * P1_TILE + (uint32_t)k * P1_THREADS + tid;
+      live[k] = idx[k] < n;
+      if (live[k]) sc[k] = load_scalar<MONT>(scalars, idx[k]);
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < P1_PER_THREAD; ++k)
+      if (live[k])
+        for_each_digit(sc[k], idx[k], G.c, G.W, G.D, G.B,
+                       [&](uint32_t g, uint32_t) { atomicAdd(&h[g >> G.sh], 1u); });
     __syncthreads();
     // reserve this tile's run in every partition; h[] becomes the running write cursor
     for (uint32_t b = tid; b < G.bins1; b += P1_THREADS) {
@@ -191,22 +201,17 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
     // back, then the four stores (one scalar at a time the rank -> store chain is pure latency)
     constexpr int U = 4;
     static_assert(P1_PER_THREAD % U == 0, "P1_PER_THREAD must be a multiple of the unroll");
+#pragma unroll
     for (int k0 = 0; k0 < P1_PER_THREAD; k0 += U) {
       DigitWalker wk[U];
-      uint32_t idx[U];
-      bool live[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        idx[u] = tile * P1_TILE + (k0 + u) * P1_THREADS + tid;
-        live[u] = idx[u] < n;
-        if (live[u]) wk[u].sc = load_scalar<MONT>(scalars, idx[u]);
-      }
+      for (int u = 0; u < U; ++u) wk[u].sc = sc[k0 + u];
       for (int w = 0; w < G.W; ++w) {
         uint32_t g[U], e[U], pos[U];
         bool v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          v[u] = live[u] && wk[u].next(w, idx[u], G.c, G.D, G.B, &g[u], &e[u]);
+          v[u] = live[k0 + u] && wk[u].next(w, idx[k0 + u], G.c, G.D, G.B, &g[u], &e[u]);
           if (v[u]) pos[u] = atomicAdd(&h[g[u] >> G.sh], 1u);
         }
 #pragma unroll
