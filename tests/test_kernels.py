@@ -109,7 +109,8 @@ def test_witness_map_circuit2(lib, golden):
     assert H.fr_from_mont_arr(h) == want
 
 
-@pytest.mark.parametrize("n,c,planes", [(5, 3, 0), (40, 4, 1), (40, 4, 3), (300, 7, 0), (300, 6, 2)])
+@pytest.mark.parametrize("n,c,planes", [(5, 3, 0), (40, 4, 1), (40, 4, 3), (300, 7, 0), (300, 6, 2),
+                                        (60, 17, 0), (60, 19, 5)])  # large windows: long offsets in the bucket reduction
 def test_msm_vs_oracle(lib, n, c, planes):
     """G1 and G2 MSM through the resident-query entry points, several window/plane layouts"""
     import circom_compat_amd as cc
