@@ -33,7 +33,7 @@ import numpy as np
 from . import _binding as B
 from ._binding import G16Error, SerializationError, SynthesisError  # noqa: F401
 
-__all__ = ["read_zkey", "R1CSFile", "R1CS", "CircomCircuit", "CircomReduction", "LibsnarkReduction", "Groth16",
+__all__ = ["read_zkey", "R1CSFile", "R1CS", "CircomCircuit", "CircomBuilder", "CircomReduction", "LibsnarkReduction", "Groth16",
            "Prover", "ProvingKey", "VerifyingKey", "ConstraintMatrices", "Proof", "G16Error",
            "SynthesisError", "SerializationError", "fr_from_ints", "fr_to_ints", "read_wtns",
            "trapdoor_setup", "Csr", "write_zkey"]
@@ -292,11 +292,25 @@ class CircomCircuit:
         self.r1cs = r1cs
         self.witness = witness
 
+    def full_assignment(self):
+        """The assignment CircomCircuit::generate_constraints builds (reference
+        src/circom/circuit.rs:35-58): variable i takes witness[wire_mapping[i]] when the mapping is
+        Some (what R1CS::from produces), witness[i] when it is None (what CircomBuilder::setup
+        leaves, src/circom/builder.rs:84-85)."""
+        w = self.witness
+        m = getattr(self.r1cs, "wire_mapping", None)
+        if w is None or m is None:
+            return w
+        n = self.r1cs.num_variables
+        if isinstance(w, np.ndarray):
+            return np.ascontiguousarray(w.reshape(-1, 4)[np.asarray(m[:n], dtype=np.int64)])
+        return [w[m[i]] for i in range(n)]
+
     def first_unsatisfied(self, lib: Optional[B.Library] = None, device=0) -> int:
         """row index of the first constraint (A.w)(B.w) != C.w, or -1: the debug-build check of
         CircomBuilder::build (reference src/circom/builder.rs:101-114) as a GPU kernel"""
         lib = lib or B.load()
-        w = _as_fr(self.witness, lib)
+        w = _as_fr(self.full_assignment(), lib)
         a, b, c = self.r1cs.a.to_c(), self.r1cs.b.to_c(), self.r1cs.c.to_c()
         out = C.c_int64(-2)
         lib.check(lib.g16_check_satisfied(device, C.byref(a), C.byref(b), C.byref(c),
@@ -315,6 +329,32 @@ class CircomCircuit:
         if m is None:
             return [w[i] for i in range(1, self.r1cs.num_inputs)]
         return [w[m[i]] for i in range(1, self.r1cs.num_inputs)]
+
+
+class CircomBuilder:
+    """CircomBuilder (reference src/circom/builder.rs:60-117) minus the WASM witness calculator, which
+    is out of scope: the witness comes from outside (snarkjs .wtns, JSON, another generator).  What
+    it keeps is the part the proving path depends on: setup() / build() hand out circuits whose
+    wire mapping is DISABLED (builder.rs:84-85), because circom witnesses are already in wire order
+    -- so get_public_inputs(), the satisfiability check and Groth16.prove all read w[i]."""
+
+    def __init__(self, r1cs: "R1CS"):
+        self.r1cs = r1cs
+
+    def setup(self) -> "CircomCircuit":
+        import copy
+        r = copy.copy(self.r1cs)
+        r.wire_mapping = None  # "Disable the wire mapping"
+        return CircomCircuit(r, None)
+
+    def build(self, witness, sanity_check=False, lib=None) -> "CircomCircuit":
+        c = self.setup()
+        c.witness = witness
+        if sanity_check:  # the debug_assert of builder.rs:101-114 as a kernel
+            bad = c.first_unsatisfied(lib)
+            if bad >= 0:
+                raise G16Error(B.G16_ERR_INVALID, f"Unsatisfied constraint: {bad}")
+        return c
 
 
 class Proof:
@@ -338,13 +378,19 @@ class Prover:
 
     def __init__(self, pk: Optional[ProvingKey], matrices: ConstraintMatrices, device=0, rank=0,
                  world=1, window_bits=0, planes=0, lib: Optional[B.Library] = None,
-                 n_vars: Optional[int] = None, dist_wm=False, reduction: str = "circom"):
+                 n_vars: Optional[int] = None, dist_wm=False, reduction: str = "circom",
+                 devices: Optional[Sequence[int]] = None):
+        """devices=[d0, d1, ...]: ONE ctx sharded over several GPUs inside the library
+        (g16_ctx_create_multi); prove() / prove_dev() are then used exactly as on one device."""
         self.lib = lib or B.load()
         self.matrices = matrices
         self.pk = pk
         if pk is None:  # witness-map-only context (R1CSToQAP use)
             if n_vars is None:
-                n_vars = matrices.num_instance_variables + matrices.num_witness_variables - 1
+                # the two producers of ConstraintMatrices disagree on num_witness_variables
+                # (read_zkey: n_vars - n_public, src/zkey.rs:183; R1CS: n_wires - num_inputs), so the
+                # witness length cannot be derived from the counts: it is max wire index + 1 at least
+                raise G16Error(B.G16_ERR_INVALID, "a witness-map-only Prover needs n_vars (len(full_assignment))")
             need = matrices.num_constraints + matrices.num_instance_variables
             dom = 1
             while dom < need:
@@ -364,8 +410,15 @@ class Prover:
         self.rank, self.world = rank, world
         a, b = matrices.a.to_c(), matrices.b.to_c()
         ctx = C.c_void_p()
-        st = self.lib.g16_ctx_create(C.byref(kd), C.byref(a), C.byref(b), matrices.num_constraints,
-                                     C.byref(opt), C.byref(ctx))
+        self.devices = list(devices) if devices is not None else None
+        if self.devices is not None:
+            opt.dist_wm = -1 if dist_wm is None else 0   # None: force a replicated witness map
+            ids = (C.c_int * len(self.devices))(*self.devices)
+            st = self.lib.g16_ctx_create_multi(C.byref(kd), C.byref(a), C.byref(b), matrices.num_constraints,
+                                               ids, len(self.devices), C.byref(opt), C.byref(ctx))
+        else:
+            st = self.lib.g16_ctx_create(C.byref(kd), C.byref(a), C.byref(b), matrices.num_constraints,
+                                         C.byref(opt), C.byref(ctx))
         self.lib.check(st, None)
         self.ctx = ctx
 
@@ -457,6 +510,36 @@ class Prover:
     def witness_buffer(self) -> int:
         return int(self.lib.g16_witness_buffer(self.ctx) or 0)
 
+    def witness_host_buffer(self) -> np.ndarray:
+        """(n_vars, 4) uint64 view of the ctx's page-locked staging buffer (g16_witness_host_buffer)"""
+        p = self.lib.g16_witness_host_buffer(self.ctx)
+        if not p:
+            raise G16Error(B.G16_ERR_HIP, "pinned allocation failed")
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(self.n_vars * 4,))
+        return arr.reshape(self.n_vars, 4)
+
+    # -- device-side hand-offs for a host framework that owns a stream (torch + RCCL)
+    def set_exchange_stream(self, hip_stream: int, enabled=True):
+        self.lib.check(self.lib.g16_dist_set_exchange_stream(self.ctx, C.c_void_p(hip_stream),
+                                                             1 if enabled else 0), self.ctx)
+
+    def partial_buffer(self) -> int:
+        return int(self.lib.g16_partial_buffer(self.ctx) or 0)
+
+    def gather_buffer(self) -> int:
+        return int(self.lib.g16_gather_buffer(self.ctx) or 0)
+
+    def dist_phase3_dev(self, recv_ptr: int):
+        """phase 3 with the record left in partial_buffer() (needs set_exchange_stream)"""
+        self.lib.check(self.lib.g16_prove_dist_phase3(self.ctx, C.c_void_p(recv_ptr), None), self.ctx)
+
+    def prove_finish_dev(self, r, s) -> Proof:
+        rs = _as_fr([r, s], self.lib) if not isinstance(r, np.ndarray) else np.stack([r, s])
+        out = np.empty(B.G16_PROOF_BYTES, dtype=np.uint8)
+        self.lib.check(self.lib.g16_prove_finish_dev(self.ctx, _np_ptr(rs[0:1]), _np_ptr(rs[1:2]),
+                                                     _np_ptr(out)), self.ctx)
+        return Proof(out.tobytes())
+
     def set_profiling(self, on: bool):
         self.lib.check(self.lib.g16_set_profiling(self.ctx, 1 if on else 0), self.ctx)
 
@@ -471,7 +554,7 @@ class Prover:
         out = (C.c_uint32 * 16)()
         self.lib.check(self.lib.g16_ctx_info(self.ctx, out), self.ctx)
         keys = ["c_w", "W_w", "planes_w", "D_w", "c_h", "W_h", "planes_h", "D_h", "domain_size",
-                "log_n", "shard_w", "shard_h"]
+                "log_n", "shard_w", "shard_h", "devices"]
         return dict(zip(keys, list(out)))
 
 
@@ -604,8 +687,8 @@ class Groth16:
         rng = rng or random.SystemRandom()
         r = rng.randrange(FR_MODULUS)
         s = rng.randrange(FR_MODULUS)
-        w = circuit.witness
-        if circuit.r1cs.wire_mapping is not None and not isinstance(w, np.ndarray):
-            pass  # circom witnesses are already in wire order; the mapping only relabels signals
+        # the assignment generate_constraints would allocate (circuit.rs:35-58): through the wire
+        # mapping when the circuit carries one, so that it matches get_public_inputs()
+        w = circuit.full_assignment()
         return Groth16.create_proof_with_reduction_and_matrices(
             pk, r, s, matrices, matrices.num_instance_variables, matrices.num_constraints, w, **kw)

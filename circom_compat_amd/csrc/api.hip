@@ -8,65 +8,19 @@
 
 #include <mutex>
 
-#include "finalize.h"
-#include "msm.h"
-#include "witness_map.h"
-#include "wm_dist.h"
+#include "ctx.h"
+
+using namespace g16;
 
 static_assert(offsetof(g16::ProofSums, B1) == sizeof(g16::G1XYZZ29) && offsetof(g16::ProofSums, L) == 2 * sizeof(g16::G1XYZZ29),
               "ProofSums must keep A, B1, L adjacent (batched reduction writes them as an array)");
 static_assert(G16_PARTIAL_BYTES == g16::FIN_PARTIAL_BYTES, "partial record size out of sync");
-
-using namespace g16;
 
 namespace {
 std::mutex g_err_mu;
 std::string g_create_error;
 }  // namespace
 
-struct g16_ctx {
-  int device = 0, rank = 0, world = 1;
-  uint32_t N = 0, p = 0, n = 0, m = 0, num_inputs = 0;
-  bool has_key = false;  // false: witness-map-only context (a_query == NULL at create)
-  bool overlap = true;   // G16_NO_OVERLAP=1: everything on one stream (A/B measurements)
-  hipStream_t stream = nullptr;
-  hipStream_t side = nullptr;  // finalize stages that overlap the MSMs
-  hipStream_t aux = nullptr;   // witness map + H-query sort, beside the witness-scalar MSMs
-  hipStream_t red = nullptr;   // G2 bucket reduction, underneath the H MSM
-  hipEvent_t ev_start = nullptr, ev_ab = nullptr, ev_side = nullptr, ev_w = nullptr, ev_h = nullptr,
-             ev_b2 = nullptr, ev_fixed = nullptr;
-  hipEvent_t ev_acc[3] = {nullptr, nullptr, nullptr};
-  std::string err;
-
-  WitnessMap wm;
-  WmDist wd;             // distributed witness map (options.dist_wm, world > 1)
-  bool dist_wm = false;
-  // sharded provers: r/s-only finalisation sums already enqueued on the side stream by the
-  // partial / phase-1 call for these (r, s)
-  bool fixed_ready = false;
-  uint64_t fixed_rs[8] = {0};
-  // shard of the assignment-index space [0, N-1) (entry i <-> w[1+i]) and of [0, n) for H
-  uint32_t w_lo = 0, w_hi = 0, h_lo = 0, h_hi = 0;
-  uint32_t l_idx_min = 0;  // entries below this local index have no L point (public inputs)
-  MsmConfig cfg_w, cfg_h;
-  MsmSort sort_w, sort_h;
-  MsmPoints<Fq> ptsA, ptsB1, ptsL, ptsH;
-  MsmPoints<Fq2> ptsB2;
-  MsmWork<Fq> work1, workH;  // witness-scalar G1 MSMs (A, B1, L) / H MSM
-  MsmWork<Fq2> work2;
-
-  DevBuf<Fr> w_dev, h_dev, rs_dev;  // h_dev: storage form (g16_witness_map / g16_msm_g1 staging)
-  DevBuf<U256> h_canon;             // h as canonical integers: scalars of the H-query MSM
-  DevBuf<KeyHeaderDev> key_dev;
-  DevBuf<ProofSums> sums_dev;
-  DevBuf<FinTables> fin_tab;
-  DevBuf<FinScratch> fin_scr;
-  DevBuf<uint8_t> out_dev;  // proof (256) | partial (384) | gathered partials
-
-  StageTimer timer;
-  float st_ms[ST_COUNT] = {0};
-  uint32_t st_cnt[ST_COUNT] = {0};
-};
 
 namespace {
 
@@ -262,6 +216,79 @@ g16_status check_w(g16_ctx* c, size_t n_vars) {
 
 }  // namespace
 
+namespace g16 {
+
+void rank_collect_times(g16_ctx* c) { collect_times(c); }
+
+// this rank's r*A-side products: s*A and r*B1 (variable-base, one wave each) overlap its L / B2 / H MSMs
+static void fork_partial_var(g16_ctx* c, hipStream_t from) {
+  G16_HIP(hipEventRecord(c->ev_ab, from));
+  G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
+  fin_partial_var(c->sums_dev.p, c->rs_dev.p, c->side);
+}
+
+void rank_partial_enqueue(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], const Fr* w_dev) {
+  G16_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  begin_sharded(c, r, s_);
+  run_msms(c, w_dev, [&](hipStream_t from) { fork_partial_var(c, from); });
+  G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));
+  sums_to_partial(c->sums_dev.p, c->part_dev(), s);
+  G16_HIP(hipEventRecord(c->ev_part, s));
+}
+
+void rank_phase1_enqueue(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], const Fr* w_dev,
+                         int32_t* send_dev) {
+  G16_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream, x = c->aux;
+  begin_sharded(c, r, s_);
+  G16_HIP(hipEventRecord(c->ev_w, s));
+  G16_HIP(hipStreamWaitEvent(x, c->ev_w, 0));
+  c->wd.phase1(w_dev, send_dev, x);
+  G16_HIP(hipEventRecord(c->ev_send, x));
+  // the witness-scalar MSMs of this rank's point range run on the main stream during both
+  // exchanges and phases 2-3
+  enqueue_witness_msms(c, w_dev, [&](hipStream_t from) { fork_partial_var(c, from); }, [] {});
+}
+
+void rank_phase2_enqueue(g16_ctx* c, const int32_t* recv_dev, int32_t* send_dev) {
+  G16_HIP(hipSetDevice(c->device));
+  c->wd.phase2(recv_dev, send_dev, c->aux);
+  G16_HIP(hipEventRecord(c->ev_send, c->aux));
+}
+
+void rank_phase3_enqueue(g16_ctx* c, const int32_t* recv_dev) {
+  G16_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream, x = c->aux;
+  c->wd.phase3(recv_dev, c->h_canon.p, x);
+  c->sort_h.run(c->h_canon.p, c->h_hi - c->h_lo, /*mont=*/false, x);
+  G16_HIP(hipEventRecord(c->ev_h, x));
+  enqueue_h_msm(c);
+  G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));
+  sums_to_partial(c->sums_dev.p, c->part_dev(), s);
+  G16_HIP(hipEventRecord(c->ev_part, s));
+}
+
+void rank_finish_enqueue(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], int world) {
+  G16_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  uint64_t rs[8];
+  memcpy(rs, r, 32);
+  memcpy(rs + 4, s_, 32);
+  partials_to_sums(c->gathered_dev(), world, c->sums_dev.p, s);
+  // the r/s-only sums were started by this ctx's partial / phase-1 call when (r, s) match (side
+  // stream; ev_side was joined by the main stream before the record was written)
+  if (!(c->fixed_ready && memcmp(c->fixed_rs, rs, 64) == 0)) {
+    memcpy(c->fixed_rs, rs, 64);
+    G16_HIP(hipMemcpyAsync(c->rs_dev.p, c->fixed_rs, 64, hipMemcpyHostToDevice, s));
+    fin_fixed_dist(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, s);
+  }
+  c->fixed_ready = false;
+  fin_final_dist(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, s);
+}
+
+}  // namespace g16
+
 extern "C" {
 
 const char* g16_last_error(const g16_ctx* ctx) {
@@ -280,7 +307,22 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
   if (opt) o = *opt;
   if (o.world <= 0) o.world = 1;
   if (o.rank < 0 || o.rank >= o.world) return fail(nullptr, G16_ERR_INVALID, "bad rank/world");
-  if (key->n_vars < key->n_public + 1) return fail(nullptr, G16_ERR_INVALID, "n_vars < n_public+1");
+  if ((uint64_t)key->n_vars < (uint64_t)key->n_public + 1)
+    return fail(nullptr, G16_ERR_INVALID, "n_vars < n_public+1");
+  // the kernels index w[col[j]] and col/coeff[row_ptr[i] .. row_ptr[i+1]) unchecked: validate once
+  // here (the reference panics on an out-of-bounds wire index in evaluate_constraint)
+  for (const g16_csr* mtx : {a, b}) {
+    if (!mtx->row_ptr || (mtx->nnz && (!mtx->col || !mtx->coeff)))
+      return fail(nullptr, G16_ERR_INVALID, "matrix with null arrays");
+    if (mtx->row_ptr[0] != 0 || mtx->row_ptr[num_constraints] != mtx->nnz)
+      return fail(nullptr, G16_ERR_INVALID, "matrix row_ptr does not span [0, nnz]");
+    for (uint32_t i = 0; i < num_constraints; ++i)
+      if (mtx->row_ptr[i] > mtx->row_ptr[i + 1])
+        return fail(nullptr, G16_ERR_INVALID, "matrix row_ptr is not monotone");
+    for (uint64_t j = 0; j < mtx->nnz; ++j)
+      if (mtx->col[j] >= key->n_vars)
+        return fail(nullptr, G16_ERR_INVALID, "matrix wire index >= n_vars");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, G16_ERR_NO_DEVICE,
@@ -314,6 +356,9 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     G16_HIP(hipEventCreateWithFlags(&c->ev_b2, hipEventDisableTiming));
     for (auto& e : c->ev_acc) G16_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_fixed, hipEventDisableTiming));
+    G16_HIP(hipEventCreateWithFlags(&c->ev_send, hipEventDisableTiming));
+    G16_HIP(hipEventCreateWithFlags(&c->ev_part, hipEventDisableTiming));
+    G16_HIP(hipEventCreateWithFlags(&c->ev_user, hipEventDisableTiming));
     hipStream_t s = c->stream;
     c->N = key->n_vars;
     c->p = key->n_public;
@@ -410,6 +455,7 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     memcpy(&kh.delta2, key->delta_g2, 128);
     memcpy(&kh.b2_0, key->b_g2_query, 128);
     G16_HIP(hipMemcpyAsync(c->key_dev.p, &kh, sizeof kh, hipMemcpyHostToDevice, s));
+    G16_HIP(hipMemsetAsync(c->out_dev.p, 0, c->out_dev.bytes(), s));
     G16_HIP(hipMemsetAsync(c->sums_dev.p, 0, sizeof(ProofSums), s));  // all sums = infinity
     G16_HIP(hipMemsetAsync(c->fin_scr.p, 0, sizeof(FinScratch), s));
     fin_build_tables(c->key_dev.p, c->fin_tab.p, s);
@@ -430,6 +476,11 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
 
 void g16_ctx_destroy(g16_ctx* c) {
   if (!c) return;
+  if (c->multi) {  // parent of a multi-device prover: the children own all device state
+    multi_destroy(c->multi);
+    delete c;
+    return;
+  }
   (void)hipSetDevice(c->device);
   if (c->side) {
     (void)hipStreamSynchronize(c->side);
@@ -456,11 +507,16 @@ void g16_ctx_destroy(g16_ctx* c) {
   for (auto e : c->ev_acc)
     if (e) (void)hipEventDestroy(e);
   if (c->ev_fixed) (void)hipEventDestroy(c->ev_fixed);
+  if (c->ev_send) (void)hipEventDestroy(c->ev_send);
+  if (c->ev_part) (void)hipEventDestroy(c->ev_part);
+  if (c->ev_user) (void)hipEventDestroy(c->ev_user);
+  if (c->pinned_w) (void)hipHostFree(c->pinned_w);
   delete c;
 }
 
 g16_status g16_witness_map(g16_ctx* c, const uint64_t* w, size_t n_vars, uint64_t* h_out) {
   if (!c || !w || !h_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx proves only (g16_prove)");
   if (c->dist_wm) return fail(c, G16_ERR_INVALID, "dist_wm ctx holds 1/world of the witness map");
   if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
   return guarded(c, [&]() -> g16_status {
@@ -476,6 +532,7 @@ g16_status g16_witness_map(g16_ctx* c, const uint64_t* w, size_t n_vars, uint64_
 static g16_status msm_common(g16_ctx* c, int which, bool g2, const uint64_t* scalars, size_t len,
                              uint8_t* out) {
   if (!c || !scalars || !out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx proves only (g16_prove)");
   if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
   if (c->world != 1) return fail(c, G16_ERR_INVALID, "g16_msm_* needs a world == 1 ctx");
   return guarded(c, [&]() -> g16_status {
@@ -532,6 +589,10 @@ g16_status g16_msm_g2(g16_ctx* c, const uint64_t* scalars, size_t len, uint8_t o
 g16_status g16_prove_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], const void* w_dev,
                          size_t n_vars, uint8_t proof_out[G16_PROOF_BYTES]) {
   if (!c || !r || !s_ || !w_dev || !proof_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) {  // sharded transparently over the devices of g16_ctx_create_multi
+    if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+    return multi_prove(c, r, s_, w_dev, /*w_on_device=*/true, proof_out);
+  }
   if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
   if (c->world != 1) return fail(c, G16_ERR_INVALID, "g16_prove needs world == 1; use partial/finish");
   if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
@@ -574,6 +635,10 @@ g16_status g16_prove(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], cons
                      size_t n_vars, uint8_t proof_out[G16_PROOF_BYTES]) {
   if (!c || !w) return fail(c, G16_ERR_INVALID, "null argument");
   if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+  if (c->multi) {
+    if (!r || !s_ || !proof_out) return fail(c, G16_ERR_INVALID, "null argument");
+    return multi_prove(c, r, s_, w, /*w_on_device=*/false, proof_out);
+  }
   g16_status st = guarded(c, [&]() -> g16_status {
     G16_HIP(hipMemcpyAsync(c->w_dev.p, w, (size_t)c->N * 32, hipMemcpyHostToDevice, c->stream));
     return G16_OK;
@@ -586,22 +651,14 @@ g16_status g16_prove_partial_dev(g16_ctx* c, const uint64_t r[4], const uint64_t
                                  const void* w_dev, size_t n_vars,
                                  uint8_t partial_out[G16_PARTIAL_BYTES]) {
   if (!c || !r || !s_ || !w_dev || !partial_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx: use g16_prove");
   if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
   if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
   if (c->dist_wm) return fail(c, G16_ERR_INVALID, "dist_wm ctx: use the g16_prove_dist_phase* calls");
   return guarded(c, [&]() -> g16_status {
     hipStream_t s = c->stream;
-    begin_sharded(c, r, s_);
-    run_msms(c, (const Fr*)w_dev, [&](hipStream_t from) {
-      // this rank's s*A and r*B1 (variable-base, one wave each) overlap its L / B2 / H MSMs
-      G16_HIP(hipEventRecord(c->ev_ab, from));
-      G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
-      fin_partial_var(c->sums_dev.p, c->rs_dev.p, c->side);
-    });
-    G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));
-    uint8_t* part = c->out_dev.p + G16_PROOF_BYTES;
-    sums_to_partial(c->sums_dev.p, part, s);
-    G16_HIP(hipMemcpyAsync(partial_out, part, G16_PARTIAL_BYTES, hipMemcpyDeviceToHost, s));
+    rank_partial_enqueue(c, r, s_, (const Fr*)w_dev);
+    G16_HIP(hipMemcpyAsync(partial_out, c->part_dev(), G16_PARTIAL_BYTES, hipMemcpyDeviceToHost, s));
     G16_HIP(hipStreamSynchronize(s));
     collect_times(c);
     return G16_OK;
@@ -612,6 +669,7 @@ g16_status g16_prove_partial(g16_ctx* c, const uint64_t r[4], const uint64_t s_[
                              const uint64_t* w, size_t n_vars,
                              uint8_t partial_out[G16_PARTIAL_BYTES]) {
   if (!c || !w) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx: use g16_prove");
   if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
   g16_status st = guarded(c, [&]() -> g16_status {
     G16_HIP(hipMemcpyAsync(c->w_dev.p, w, (size_t)c->N * 32, hipMemcpyHostToDevice, c->stream));
@@ -625,89 +683,120 @@ g16_status g16_prove_finish(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4
                             const uint8_t* partials, int world,
                             uint8_t proof_out[G16_PROOF_BYTES]) {
   if (!c || !r || !s_ || !partials || !proof_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx: use g16_prove");
   if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
   if (world != c->world) return fail(c, G16_ERR_INVALID, "world does not match the ctx");
   return guarded(c, [&]() -> g16_status {
     hipStream_t s = c->stream;
-    uint64_t rs[8];
-    memcpy(rs, r, 32);
-    memcpy(rs + 4, s_, 32);
-    G16_HIP(hipMemcpyAsync(c->rs_dev.p, rs, 64, hipMemcpyHostToDevice, s));
-    uint8_t* gathered = c->out_dev.p + G16_PROOF_BYTES + G16_PARTIAL_BYTES;
-    G16_HIP(hipMemcpyAsync(gathered, partials, (size_t)world * G16_PARTIAL_BYTES,
+    G16_HIP(hipMemcpyAsync(c->gathered_dev(), partials, (size_t)world * G16_PARTIAL_BYTES,
                            hipMemcpyHostToDevice, s));
-    partials_to_sums(gathered, world, c->sums_dev.p, s);
-    // the r/s-only sums were started by this ctx's partial / phase-1 call when (r, s) match
-    // (side stream, complete: that call joined the side stream before returning its record)
-    if (!(c->fixed_ready && memcmp(c->fixed_rs, rs, 64) == 0))
-      fin_fixed_dist(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, s);
-    c->fixed_ready = false;
-    fin_final_dist(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, s);
+    rank_finish_enqueue(c, r, s_, world);
     G16_HIP(hipMemcpyAsync(proof_out, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
     G16_HIP(hipStreamSynchronize(s));
     return G16_OK;
   });
 }
 
-size_t g16_dist_exchange_bytes(const g16_ctx* c) {
-  return (c && c->dist_wm) ? c->wd.exchange_ints() * sizeof(int32_t) : 0;
-}
+void* g16_partial_buffer(g16_ctx* c) { return (c && !c->multi && c->has_key) ? (void*)c->part_dev() : nullptr; }
+void* g16_gather_buffer(g16_ctx* c) { return (c && !c->multi && c->has_key) ? (void*)c->gathered_dev() : nullptr; }
 
-g16_status g16_prove_dist_phase1(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4],
-                                 const void* w_dev, size_t n_vars, void* send_dev) {
-  if (!c || !r || !s_ || !w_dev || !send_dev) return fail(c, G16_ERR_INVALID, "null argument");
-  if (!c->dist_wm || !c->has_key) return fail(c, G16_ERR_INVALID, "not a dist_wm proving ctx");
-  if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+g16_status g16_prove_finish_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4],
+                                uint8_t proof_out[G16_PROOF_BYTES]) {
+  if (!c || !r || !s_ || !proof_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx: use g16_prove");
+  if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
   return guarded(c, [&]() -> g16_status {
-    hipStream_t s = c->stream, x = c->aux;
-    begin_sharded(c, r, s_);
-    G16_HIP(hipEventRecord(c->ev_w, s));
-    G16_HIP(hipStreamWaitEvent(x, c->ev_w, 0));
-    c->wd.phase1((const Fr*)w_dev, (int32_t*)send_dev, x);
-    // the witness-scalar MSMs of this rank's point range run on the main stream during both
-    // exchanges and phases 2-3
-    enqueue_witness_msms(c, (const Fr*)w_dev, [&](hipStream_t from) {
-      G16_HIP(hipEventRecord(c->ev_ab, from));
-      G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
-      fin_partial_var(c->sums_dev.p, c->rs_dev.p, c->side);
-    }, [] {});
-    G16_HIP(hipStreamSynchronize(x));  // send buffer complete; the main stream keeps running
-    return G16_OK;
-  });
-}
-
-g16_status g16_prove_dist_phase2(g16_ctx* c, const void* recv_dev, void* send_dev) {
-  if (!c || !recv_dev || !send_dev) return fail(c, G16_ERR_INVALID, "null argument");
-  if (!c->dist_wm) return fail(c, G16_ERR_INVALID, "not a dist_wm ctx");
-  return guarded(c, [&]() -> g16_status {
-    c->wd.phase2((const int32_t*)recv_dev, (int32_t*)send_dev, c->aux);
-    G16_HIP(hipStreamSynchronize(c->aux));
-    return G16_OK;
-  });
-}
-
-g16_status g16_prove_dist_phase3(g16_ctx* c, const void* recv_dev,
-                                 uint8_t partial_out[G16_PARTIAL_BYTES]) {
-  if (!c || !recv_dev || !partial_out) return fail(c, G16_ERR_INVALID, "null argument");
-  if (!c->dist_wm || !c->has_key) return fail(c, G16_ERR_INVALID, "not a dist_wm proving ctx");
-  return guarded(c, [&]() -> g16_status {
-    hipStream_t s = c->stream, x = c->aux;
-    c->wd.phase3((const int32_t*)recv_dev, c->h_canon.p, x);
-    c->sort_h.run(c->h_canon.p, c->h_hi - c->h_lo, /*mont=*/false, x);
-    G16_HIP(hipEventRecord(c->ev_h, x));
-    enqueue_h_msm(c);
-    G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));
-    uint8_t* part = c->out_dev.p + G16_PROOF_BYTES;
-    sums_to_partial(c->sums_dev.p, part, s);
-    G16_HIP(hipMemcpyAsync(partial_out, part, G16_PARTIAL_BYTES, hipMemcpyDeviceToHost, s));
+    hipStream_t s = c->stream;
+    if (c->have_xstream) {  // the all-gather into gathered_dev() was enqueued on the exchange stream
+      G16_HIP(hipEventRecord(c->ev_user, c->xstream));
+      G16_HIP(hipStreamWaitEvent(s, c->ev_user, 0));
+    }
+    rank_finish_enqueue(c, r, s_, c->world);
+    G16_HIP(hipMemcpyAsync(proof_out, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
     G16_HIP(hipStreamSynchronize(s));
     collect_times(c);
     return G16_OK;
   });
 }
 
+g16_status g16_dist_set_exchange_stream(g16_ctx* c, void* hip_stream, int enabled) {
+  if (!c || c->multi) return fail(c, G16_ERR_INVALID, "not a per-rank ctx");
+  c->xstream = (hipStream_t)hip_stream;
+  c->have_xstream = enabled != 0;
+  return G16_OK;
+}
+
+size_t g16_dist_exchange_bytes(const g16_ctx* c) {
+  return (c && c->dist_wm) ? c->wd.exchange_ints() * sizeof(int32_t) : 0;
+}
+
+// Hand-off to the host framework's collective.  With an exchange stream registered the caller's
+// stream is made to wait for the event (the host never blocks); without one the call blocks until
+// the buffer is complete, which is what a framework that cannot share a stream needs.
+static void handoff(g16_ctx* c, hipEvent_t ev, hipStream_t producer) {
+  if (c->have_xstream) G16_HIP(hipStreamWaitEvent(c->xstream, ev, 0));
+  else G16_HIP(hipStreamSynchronize(producer));
+}
+// ... and back: what the caller enqueued on the exchange stream so far precedes `consumer`
+static void handback(g16_ctx* c, hipStream_t consumer) {
+  if (!c->have_xstream) return;  // blocking collectives: already complete when the call is made
+  G16_HIP(hipEventRecord(c->ev_user, c->xstream));
+  G16_HIP(hipStreamWaitEvent(consumer, c->ev_user, 0));
+}
+
+g16_status g16_prove_dist_phase1(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4],
+                                 const void* w_dev, size_t n_vars, void* send_dev) {
+  if (!c || !r || !s_ || !w_dev || !send_dev) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx: use g16_prove");
+  if (!c->dist_wm || !c->has_key) return fail(c, G16_ERR_INVALID, "not a dist_wm proving ctx");
+  if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+  return guarded(c, [&]() -> g16_status {
+    handback(c, c->stream);  // w_dev may have been produced on the caller's stream
+    rank_phase1_enqueue(c, r, s_, (const Fr*)w_dev, (int32_t*)send_dev);
+    handoff(c, c->ev_send, c->aux);  // send buffer complete; the main stream keeps running
+    return G16_OK;
+  });
+}
+
+g16_status g16_prove_dist_phase2(g16_ctx* c, const void* recv_dev, void* send_dev) {
+  if (!c || !recv_dev || !send_dev) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx: use g16_prove");
+  if (!c->dist_wm) return fail(c, G16_ERR_INVALID, "not a dist_wm ctx");
+  return guarded(c, [&]() -> g16_status {
+    handback(c, c->aux);
+    rank_phase2_enqueue(c, (const int32_t*)recv_dev, (int32_t*)send_dev);
+    handoff(c, c->ev_send, c->aux);
+    return G16_OK;
+  });
+}
+
+g16_status g16_prove_dist_phase3(g16_ctx* c, const void* recv_dev,
+                                 uint8_t partial_out[G16_PARTIAL_BYTES]) {
+  if (!c || !recv_dev) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx: use g16_prove");
+  if (!c->dist_wm || !c->has_key) return fail(c, G16_ERR_INVALID, "not a dist_wm proving ctx");
+  if (!partial_out && !c->have_xstream)
+    return fail(c, G16_ERR_INVALID, "partial_out == NULL needs an exchange stream (g16_partial_buffer hand-off)");
+  return guarded(c, [&]() -> g16_status {
+    hipStream_t s = c->stream;
+    handback(c, c->aux);
+    rank_phase3_enqueue(c, (const int32_t*)recv_dev);
+    if (partial_out) {
+      G16_HIP(hipMemcpyAsync(partial_out, c->part_dev(), G16_PARTIAL_BYTES, hipMemcpyDeviceToHost, s));
+      G16_HIP(hipStreamSynchronize(s));
+      collect_times(c);
+    } else {
+      // device-side hand-off: the record stays in g16_partial_buffer(); the caller's all-gather
+      // (enqueued on the exchange stream) waits for it
+      G16_HIP(hipStreamWaitEvent(c->xstream, c->ev_part, 0));
+    }
+    return G16_OK;
+  });
+}
+
 g16_status g16_set_profiling(g16_ctx* c, int enabled) {
   if (!c) return G16_ERR_INVALID;
+  for (int g = 0; g < multi_size(c); ++g) g16_set_profiling(multi_child(c, g), enabled);
   c->timer.enabled = enabled != 0;
   for (int i = 0; i < ST_COUNT; ++i) {
     c->st_ms[i] = 0.f;
@@ -719,6 +808,23 @@ g16_status g16_set_profiling(g16_ctx* c, int enabled) {
 g16_status g16_stage_times(g16_ctx* c, float ms[G16_N_STAGES], uint32_t launches[G16_N_STAGES]) {
   if (!c || !ms || !launches) return G16_ERR_INVALID;
   static_assert(G16_N_STAGES == ST_COUNT, "stage table out of sync with the header");
+  if (c->multi) {  // per stage: the slowest device (the one the proof waited for)
+    for (int i = 0; i < ST_COUNT; ++i) {
+      ms[i] = 0.f;
+      launches[i] = 0;
+    }
+    for (int g = 0; g < multi_size(c); ++g) {
+      float m1[ST_COUNT];
+      uint32_t l1[ST_COUNT];
+      g16_stage_times(multi_child(c, g), m1, l1);
+      for (int i = 0; i < ST_COUNT; ++i)
+        if (m1[i] >= ms[i]) {
+          ms[i] = m1[i];
+          launches[i] = l1[i];
+        }
+    }
+    return G16_OK;
+  }
   for (int i = 0; i < ST_COUNT; ++i) {
     ms[i] = c->st_ms[i];
     launches[i] = c->st_cnt[i];
@@ -736,7 +842,13 @@ const char* g16_stage_name(int stage) {
 
 g16_status g16_ctx_info(const g16_ctx* c, uint32_t out[16]) {
   if (!c || !out) return G16_ERR_INVALID;
+  if (c->multi) {  // the shards are alike: report rank 0's configuration and the device count
+    g16_status st = g16_ctx_info(multi_child(const_cast<g16_ctx*>(c), 0), out);
+    out[12] = (uint32_t)multi_size(c);
+    return st;
+  }
   memset(out, 0, 16 * sizeof(uint32_t));
+  out[12] = 1;
   out[0] = c->cfg_w.c; out[1] = c->cfg_w.W; out[2] = c->cfg_w.Pn; out[3] = c->cfg_w.D;
   out[4] = c->cfg_h.c; out[5] = c->cfg_h.W; out[6] = c->cfg_h.Pn; out[7] = c->cfg_h.D;
   out[8] = c->n;
@@ -746,7 +858,52 @@ g16_status g16_ctx_info(const g16_ctx* c, uint32_t out[16]) {
   return G16_OK;
 }
 
-void* g16_witness_buffer(g16_ctx* c) { return c ? (void*)c->w_dev.p : nullptr; }
+void* g16_witness_buffer(g16_ctx* c) {
+  if (c && c->multi) c = multi_child(c, 0);
+  return c ? (void*)c->w_dev.p : nullptr;
+}
+
+void* g16_witness_host_buffer(g16_ctx* c) {
+  if (!c) return nullptr;
+  if (!c->pinned_w) {
+    (void)hipSetDevice(c->device);
+    void* p = nullptr;
+    // portable: a multi-device ctx uploads the same staging buffer to every device
+    if (hipHostMalloc(&p, (size_t)(c->N ? c->N : 1) * 32, hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    c->pinned_w = p;
+  }
+  return c->pinned_w;
+}
+
+g16_status g16_ctx_create_multi(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
+                                uint32_t num_constraints, const int* device_ids, int n_dev,
+                                const g16_options* opt, g16_ctx** out) {
+  if (!key || !a || !b || !out || !device_ids) return fail(nullptr, G16_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (n_dev < 1 || n_dev > 64) return fail(nullptr, G16_ERR_INVALID, "n_dev must be in [1, 64]");
+  if (!key->a_query) return fail(nullptr, G16_ERR_INVALID, "a multi-device ctx needs the proving key");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, G16_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+  for (int i = 0; i < n_dev; ++i)
+    if (device_ids[i] < 0 || device_ids[i] >= ndev) return fail(nullptr, G16_ERR_INVALID, "bad device ordinal");
+  if (n_dev == 1) {
+    g16_options o{};
+    if (opt) o = *opt;
+    o.device = device_ids[0];
+    o.rank = 0;
+    o.world = 1;
+    o.dist_wm = 0;
+    return g16_ctx_create(key, a, b, num_constraints, &o, out);
+  }
+  std::string err;
+  const g16_status st = multi_create(key, a, b, num_constraints, device_ids, n_dev, opt, out, &err);
+  if (st != G16_OK) return fail(nullptr, st, err);
+  return G16_OK;
+}
 
 g16_status g16_check_satisfied(int device, const g16_csr* a, const g16_csr* b, const g16_csr* c_,
                                uint32_t num_constraints, const uint64_t* w, size_t n_vars,

@@ -6,9 +6,13 @@
 //          read_constraint_vec :203-213, read_constraints :215-229, read_map :231-249, R1CS::from :26-39)
 // The point sections are handed out as zero-copy views: the on-disk encoding (x|y Montgomery LE,
 // all-zero = infinity) is already the device encoding.
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <map>
 #include <string>
@@ -132,8 +136,62 @@ struct CsrOwned {
 
 }  // namespace
 
+// Read-only view of a whole file.  g16_zkey_open maps the file (the 64 / 128-byte point sections are
+// handed to g16_ctx_create straight out of the page cache: no 6 GiB host copy at 2^24, and the
+// reference's one-Read-call-per-field-element loop, src/zkey.rs:328-368, becomes page faults);
+// g16_zkey_open_mem owns a copy of the caller's buffer.
+struct FileView {
+  const uint8_t* p = nullptr;
+  size_t n = 0;
+  void* map = nullptr;  // non-null: munmap on release
+  std::vector<uint8_t> own;
+  FileView() = default;
+  FileView(const FileView&) = delete;
+  FileView& operator=(const FileView&) = delete;
+  ~FileView() {
+    if (map) munmap(map, n);
+  }
+  void copy_of(const uint8_t* d, size_t len) {
+    own.assign(d, d + len);
+    p = own.data();
+    n = own.size();
+  }
+  bool map_file(const char* path, std::string& err) {
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) {
+      err = std::string("cannot open ") + path;
+      return false;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 0) {
+      close(fd);
+      err = "cannot stat file";
+      return false;
+    }
+    n = (size_t)st.st_size;
+    if (n == 0) {  // mmap of length 0 is an error; an empty file is a truncated header downstream
+      close(fd);
+      p = own.data();
+      return true;
+    }
+    void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+      err = "mmap failed";
+      n = 0;
+      return false;
+    }
+    (void)madvise(m, n, MADV_SEQUENTIAL);
+    map = m;
+    p = (const uint8_t*)m;
+    return true;
+  }
+  const uint8_t* data() const { return p; }
+  size_t size() const { return n; }
+};
+
 struct g16_zkey {
-  std::vector<uint8_t> data;
+  FileView data;
   std::map<uint32_t, Section> sec;  // first occurrence wins (get_section, zkey.rs:135-137)
   g16_zkey_header hdr;
   bool have_matrices = false;
@@ -194,16 +252,20 @@ g16_status zkey_parse(g16_zkey* z) {
   memcpy(H.gamma_g2, pts + 256, 128);
   memcpy(H.delta_g1, pts + 384, 64);
   memcpy(H.delta_g2, pts + 448, 128);
-  if (H.n_vars < H.n_public + 1) return fail(G16_ERR_IO, "zkey: n_vars < n_public + 1");
+  // 64-bit comparisons: n_public = 0xFFFFFFFF must not wrap n_public + 1 to 0
+  if ((uint64_t)H.n_public + 1 > (uint64_t)H.n_vars)
+    return fail(G16_ERR_IO, "zkey: n_vars < n_public + 1");
+  if ((uint64_t)H.n_public + 1 > (uint64_t)H.domain_size)
+    return fail(G16_ERR_IO, "zkey: domain_size < n_public + 1");
   // section sizes the proving_key() reads rely on (zkey.rs:107-111)
   struct Need {
     uint32_t id;
     uint64_t bytes;
-  } needs[] = {{3, (uint64_t)(H.n_public + 1) * 64},
+  } needs[] = {{3, ((uint64_t)H.n_public + 1) * 64},
                {5, (uint64_t)H.n_vars * 64},
                {6, (uint64_t)H.n_vars * 64},
                {7, (uint64_t)H.n_vars * 128},
-               {8, (uint64_t)(H.n_vars - H.n_public - 1) * 64},
+               {8, ((uint64_t)H.n_vars - H.n_public - 1) * 64},
                {9, (uint64_t)H.domain_size * 64}};
   for (auto& nd : needs)
     if (z->sec[nd.id].size < nd.bytes)
@@ -346,7 +408,7 @@ g16_status g16_zkey_open_mem(const uint8_t* data, size_t len, g16_zkey** out) {
   if (!data || !out) return fail(G16_ERR_INVALID, "null argument");
   *out = nullptr;
   g16_zkey* z = new g16_zkey();
-  z->data.assign(data, data + len);
+  z->data.copy_of(data, len);
   g16_status st = zkey_parse(z);
   if (st != G16_OK) {
     delete z;
@@ -361,7 +423,7 @@ g16_status g16_zkey_open(const char* path, g16_zkey** out) {
   *out = nullptr;
   g16_zkey* z = new g16_zkey();
   std::string err;
-  if (!read_file(path, z->data, err)) {
+  if (!z->data.map_file(path, err)) {
     delete z;
     return fail(G16_ERR_IO, err);
   }
@@ -453,6 +515,9 @@ g16_status g16_zkey_matrices(g16_zkey* z, g16_matrices* out) {
       memcpy(&row, rec + 4, 4);
       memcpy(&sig, rec + 8, 4);
       if (row >= nc) continue;
+      // the reference indexes full_assignment[signal] (evaluate_constraint) and panics out of
+      // bounds; the kernels would read past the witness, so a bad wire index is a load error here
+      if (sig >= z->hdr.n_vars) return fail(G16_ERR_IO, "zkey: coefficient signal index >= n_vars");
       const uint32_t at = cur[m][row]++;
       M[m]->col[at] = sig;
       // deserialize_field_fr (:322-325): the stored value is v*R^2; one Montgomery reduction

@@ -1,0 +1,403 @@
+// multi.hip -- single-process multi-device Groth16 prover: g16_ctx_create_multi / g16_prove on a
+// parent ctx whose children are one sharded rank per device.
+//
+// What is sharded (north_star: "MSM shards by point-range across the 8 GPUs ... partial sums over
+// xGMI"): every query array is cut by contiguous point range at create time, and -- when the device
+// count is a power of two -- the witness map is distributed as well (wm_dist.h: four-step NTTs whose
+// two transposes are all-to-all exchanges).  Nothing of a proof touches the host between the
+// witness upload and the 256-byte download:
+//   * exchanges are PUSHED with hipMemcpyPeerAsync, one copy stream per destination so that all
+//     seven xGMI links of a device carry one chunk each at the same time (xGMI is point-to-point:
+//     an all-to-all IS seven independent peer copies per device; there is no ring to build);
+//   * hand-offs are events: a consumer stream waits for the `arrived` events of its G producers,
+//     the 1 KiB partial records are peer-copied to device 0 behind each rank's ev_part, and the
+//     "all-reduce of partial sums" is a gather + local EC additions there (EC addition is not an
+//     ncclRedOp; the payload is 8 KiB, i.e. latency only);
+//   * one host thread per device enqueues that device's ~100 launches (a single thread would
+//     serialise 8 x 0.5 ms of launch overhead in front of a 5-7 ms rank); the threads meet at a
+//     host barrier only so that an event is RECORDED before a peer's stream is told to wait for it.
+// The emulator build (tests only) has no threads: the same stages run device after device.
+#include "ctx.h"
+
+#include <stdlib.h>
+
+#include <functional>
+#include <vector>
+
+#ifndef G16_EMU
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#endif
+
+namespace g16 {
+
+namespace {
+
+// ---- stage runner: stage k of every device completes (on the host) before stage k+1 starts ----
+struct StageRunner {
+  int n = 0;
+  std::string first_error;
+  int first_code = G16_OK;
+#ifndef G16_EMU
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv;
+  const std::vector<std::function<void(int)>>* stages = nullptr;
+  uint64_t gen = 0;      // job generation the workers wait for
+  int done = 0;          // workers that finished the current job
+  bool stop = false;
+  int bcount = 0;        // barrier state
+  uint64_t bgen = 0;
+  bool failed = false;
+#endif
+
+  void start(int count) {
+    n = count;
+#ifndef G16_EMU
+    for (int g = 1; g < n; ++g) th.emplace_back([this, g] { worker(g); });
+#endif
+  }
+  void shutdown() {
+#ifndef G16_EMU
+    {
+      std::lock_guard<std::mutex> l(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+    th.clear();
+#endif
+  }
+
+  void note(int code, const std::string& msg) {
+#ifndef G16_EMU
+    std::lock_guard<std::mutex> l(mu);
+    failed = true;
+#endif
+    if (first_code == G16_OK) {
+      first_code = code;
+      first_error = msg;
+    }
+  }
+  bool call(const std::function<void(int)>& f, int g) {
+    try {
+      f(g);
+      return true;
+    } catch (const HipError& e) {
+      note(G16_ERR_HIP, e.what());
+    } catch (const std::bad_alloc&) {
+      note(G16_ERR_INTERNAL, "host allocation failed");
+    } catch (const std::exception& e) {
+      const bool dom = std::string(e.what()).find("PolynomialDegreeTooLarge") != std::string::npos;
+      note(dom ? G16_ERR_DOMAIN_TOO_LARGE : G16_ERR_INTERNAL, e.what());
+    }
+    return false;
+  }
+
+#ifndef G16_EMU
+  void barrier() {
+    std::unique_lock<std::mutex> l(mu);
+    const uint64_t my = bgen;
+    if (++bcount == n) {
+      bcount = 0;
+      ++bgen;
+      cv.notify_all();
+    } else {
+      cv.wait(l, [&] { return bgen != my; });
+    }
+  }
+  void run_as(int g) {
+    for (size_t k = 0; k < stages->size(); ++k) {
+      bool skip;
+      {
+        std::lock_guard<std::mutex> l(mu);
+        skip = failed;
+      }
+      if (!skip) call((*stages)[k], g);
+      barrier();  // every thread passes every barrier, failed or not
+    }
+  }
+  void worker(int g) {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [&] { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen;
+      }
+      run_as(g);
+      {
+        std::lock_guard<std::mutex> l(mu);
+        ++done;
+      }
+      cv.notify_all();
+    }
+  }
+#endif
+
+  // returns G16_OK or the first failure (message in first_error)
+  int run(const std::vector<std::function<void(int)>>& st) {
+    first_code = G16_OK;
+    first_error.clear();
+#ifdef G16_EMU
+    for (auto& f : st)
+      for (int g = 0; g < n && first_code == G16_OK; ++g) call(f, g);
+#else
+    {
+      std::lock_guard<std::mutex> l(mu);
+      stages = &st;
+      failed = false;
+      done = 0;
+      ++gen;
+    }
+    cv.notify_all();
+    run_as(0);
+    {
+      std::unique_lock<std::mutex> l(mu);
+      cv.wait(l, [&] { return done == n - 1; });
+      stages = nullptr;
+    }
+#endif
+    return first_code;
+  }
+};
+
+}  // namespace
+
+struct Multi {
+  int G = 0;
+  std::vector<g16_ctx*> ch;
+  bool dist = false;    // fully sharded: the witness map is distributed too (power-of-two G)
+  size_t chunk_ints = 0;  // int32 per (source, destination) pair and exchange
+  struct Dev {
+    DevBuf<int32_t> send[2], recv[2];
+    std::vector<hipStream_t> cs;            // one copy stream per destination
+    std::vector<hipEvent_t> arrived[2];     // [exchange][dst]: my chunk has landed in dst's recv buffer
+  };
+  std::vector<std::unique_ptr<Dev>> dv;  // DevBuf is not movable
+  StageRunner pool;
+};
+
+namespace {
+
+void enable_peers(const std::vector<g16_ctx*>& ch) {
+  for (auto* a : ch)
+    for (auto* b : ch) {
+      if (a->device == b->device) continue;
+      G16_HIP(hipSetDevice(a->device));
+      (void)hipDeviceEnablePeerAccess(b->device, 0);  // already enabled / unsupported: the copies
+      (void)hipGetLastError();                        // still work (staged through the host)
+    }
+}
+
+// exchange x of rank g: its G chunks go to the G recv buffers (own chunk included), each on its
+// own stream behind the producer's ev_send
+void push_chunks(Multi& M, int g, int x) {
+  g16_ctx* c = M.ch[g];
+  Multi::Dev& me = *M.dv[g];
+  const size_t bytes = M.chunk_ints * sizeof(int32_t);
+  for (int k = 0; k < M.G; ++k) {
+    const int d = (g + k) % M.G;  // start with the own chunk, then rotate: no destination is hit by all at once
+    hipStream_t st = me.cs[d];
+    G16_HIP(hipStreamWaitEvent(st, c->ev_send, 0));
+    G16_HIP(hipMemcpyPeerAsync(M.dv[d]->recv[x].p + (size_t)g * M.chunk_ints, M.ch[d]->device,
+                               me.send[x].p + (size_t)d * M.chunk_ints, c->device, bytes, st));
+    G16_HIP(hipEventRecord(me.arrived[x][d], st));
+  }
+}
+
+void await_chunks(Multi& M, int g, int x, hipStream_t consumer) {
+  for (int src = 0; src < M.G; ++src)
+    G16_HIP(hipStreamWaitEvent(consumer, M.dv[src]->arrived[x][g], 0));
+}
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+g16_ctx* multi_child(g16_ctx* parent, int index) {
+  if (!parent || !parent->multi || index < 0 || index >= parent->multi->G) return nullptr;
+  return parent->multi->ch[index];
+}
+int multi_size(const g16_ctx* parent) { return (parent && parent->multi) ? parent->multi->G : 0; }
+
+void multi_destroy(Multi* M) {
+  if (!M) return;
+  M->pool.shutdown();
+  for (int g = 0; g < (int)M->dv.size(); ++g) {
+    if (g < (int)M->ch.size() && M->ch[g]) (void)hipSetDevice(M->ch[g]->device);
+    for (auto s : M->dv[g]->cs)
+      if (s) {
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamDestroy(s);
+      }
+    for (auto& v : M->dv[g]->arrived)
+      for (auto e : v)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& b : M->dv[g]->send) b.release();
+    for (auto& b : M->dv[g]->recv) b.release();
+  }
+  for (auto* c : M->ch) g16_ctx_destroy(c);
+  delete M;
+}
+
+g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
+                        uint32_t num_constraints, const int* device_ids, int n_dev,
+                        const g16_options* opt, g16_ctx** out, std::string* err) {
+  Multi* M = new Multi();
+  M->G = n_dev;
+  M->ch.assign(n_dev, nullptr);
+  for (int g = 0; g < n_dev; ++g) M->dv.emplace_back(new Multi::Dev());
+  // fully sharded when the four-step split exists for this many ranks (wm_dist.h): world a power
+  // of two and n1, n2 >= world; otherwise the witness map is replicated and only the MSMs shard
+  uint64_t need = (uint64_t)num_constraints + key->n_public + 1;
+  int k = 0;
+  while (((uint64_t)1 << k) < need) ++k;
+  const bool libsnark = opt && opt->reduction == G16_REDUCTION_LIBSNARK;
+  M->dist = is_pow2(n_dev) && n_dev > 1 && !libsnark && (1u << (k / 2)) >= (uint32_t)n_dev &&
+            !(opt && opt->dist_wm < 0);
+  M->pool.start(n_dev);
+  std::vector<std::string> errs(n_dev);
+  std::vector<std::function<void(int)>> st;
+  st.push_back([&](int g) {
+    g16_options o{};
+    if (opt) o = *opt;
+    o.device = device_ids[g];
+    o.rank = g;
+    o.world = n_dev;
+    o.dist_wm = M->dist ? 1 : 0;
+    g16_ctx* c = nullptr;
+    const g16_status s = g16_ctx_create(key, a, b, num_constraints, &o, &c);
+    if (s != G16_OK) {
+      errs[g] = g16_last_error(nullptr);
+      throw std::runtime_error("device " + std::to_string(device_ids[g]) + ": " + errs[g] +
+                               (s == G16_ERR_DOMAIN_TOO_LARGE ? " PolynomialDegreeTooLarge" : ""));
+    }
+    M->ch[g] = c;
+    Multi::Dev& d = *M->dv[g];
+    G16_HIP(hipSetDevice(c->device));
+    d.cs.assign(n_dev, nullptr);
+    for (auto& s2 : d.cs) G16_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    for (int x = 0; x < 2; ++x) {
+      d.arrived[x].assign(n_dev, nullptr);
+      for (auto& e : d.arrived[x]) G16_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (M->dist) {
+      const size_t ints = c->wd.exchange_ints();
+      for (int x = 0; x < 2; ++x) {
+        d.send[x].alloc(ints);
+        d.recv[x].alloc(ints);
+      }
+    }
+  });
+  int code = M->pool.run(st);
+  if (code == G16_OK) {
+    try {
+      if (M->dist) M->chunk_ints = M->ch[0]->wd.exchange_ints() / (size_t)n_dev;
+      enable_peers(M->ch);
+    } catch (const std::exception& e) {
+      code = G16_ERR_HIP;
+      M->pool.first_error = e.what();
+    }
+  }
+  if (code != G16_OK) {
+    if (err) *err = M->pool.first_error;
+    multi_destroy(M);
+    return code;
+  }
+  g16_ctx* parent = new g16_ctx();
+  parent->multi = M;
+  parent->device = M->ch[0]->device;
+  parent->world = 1;  // from the caller's point of view: g16_prove just works
+  parent->N = M->ch[0]->N;
+  parent->p = M->ch[0]->p;
+  parent->n = M->ch[0]->n;
+  parent->m = M->ch[0]->m;
+  parent->num_inputs = M->ch[0]->num_inputs;
+  parent->has_key = true;
+  *out = parent;
+  return G16_OK;
+}
+
+g16_status multi_prove(g16_ctx* parent, const uint64_t r[4], const uint64_t s_[4], const void* w,
+                       bool w_on_device, uint8_t proof_out[G16_PROOF_BYTES]) {
+  Multi& M = *parent->multi;
+  const size_t wbytes = (size_t)parent->N * 32;
+  std::vector<const Fr*> wp(M.G, nullptr);
+
+  auto stage_witness = [&](int g) {
+    g16_ctx* c = M.ch[g];
+    G16_HIP(hipSetDevice(c->device));
+    if (!w_on_device) {
+      // every device pulls its own copy over its own PCIe link
+      G16_HIP(hipMemcpyAsync(c->w_dev.p, w, wbytes, hipMemcpyHostToDevice, c->stream));
+      wp[g] = c->w_dev.p;
+    } else if (g == 0) {
+      wp[g] = (const Fr*)w;
+    } else {
+      G16_HIP(hipMemcpyPeerAsync(c->w_dev.p, c->device, w, M.ch[0]->device, wbytes, c->stream));
+      wp[g] = c->w_dev.p;
+    }
+  };
+  auto stage_gather_finish = [&](int g) {
+    g16_ctx* c = M.ch[g];
+    G16_HIP(hipSetDevice(c->device));
+    if (g != 0) {
+      if (c->timer.enabled) {  // stage timers only: the proof itself needs no host wait here
+        G16_HIP(hipStreamSynchronize(c->stream));
+        rank_collect_times(c);
+      }
+      return;
+    }
+    hipStream_t s = c->stream;
+    for (int src = 0; src < M.G; ++src) {
+      G16_HIP(hipStreamWaitEvent(s, M.ch[src]->ev_part, 0));
+      G16_HIP(hipMemcpyPeerAsync(c->gathered_dev() + (size_t)src * G16_PARTIAL_BYTES, c->device,
+                                 M.ch[src]->part_dev(), M.ch[src]->device, G16_PARTIAL_BYTES, s));
+    }
+    rank_finish_enqueue(c, r, s_, M.G);
+    G16_HIP(hipMemcpyAsync(proof_out, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
+    G16_HIP(hipStreamSynchronize(s));
+    rank_collect_times(c);
+  };
+
+  std::vector<std::function<void(int)>> st;
+  if (M.dist) {
+    st.push_back([&](int g) {
+      stage_witness(g);
+      rank_phase1_enqueue(M.ch[g], r, s_, wp[g], M.dv[g]->send[0].p);
+      push_chunks(M, g, 0);
+    });
+    st.push_back([&](int g) {
+      G16_HIP(hipSetDevice(M.ch[g]->device));
+      await_chunks(M, g, 0, M.ch[g]->aux);
+      rank_phase2_enqueue(M.ch[g], M.dv[g]->recv[0].p, M.dv[g]->send[1].p);
+      push_chunks(M, g, 1);
+    });
+    st.push_back([&](int g) {
+      G16_HIP(hipSetDevice(M.ch[g]->device));
+      await_chunks(M, g, 1, M.ch[g]->aux);
+      rank_phase3_enqueue(M.ch[g], M.dv[g]->recv[1].p);
+    });
+  } else {
+    st.push_back([&](int g) {
+      stage_witness(g);
+      rank_partial_enqueue(M.ch[g], r, s_, wp[g]);
+    });
+  }
+  st.push_back(stage_gather_finish);
+  const int code = M.pool.run(st);
+  if (code != G16_OK) {
+    parent->err = M.pool.first_error;
+    // leave no work in flight behind a failed proof
+    for (auto* c : M.ch) {
+      (void)hipSetDevice(c->device);
+      (void)hipDeviceSynchronize();
+    }
+  }
+  return code;
+}
+
+}  // namespace g16

@@ -101,6 +101,21 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
 void g16_ctx_destroy(g16_ctx* ctx);
 const char* g16_last_error(const g16_ctx* ctx); /* ctx may be NULL: error of the last failed create */
 
+/* Single-process multi-device prover (`device_ids, n_dev`; section 8(e)).
+ * One sharded rank per listed device INSIDE the library: every query is cut by contiguous point
+ * range over the devices and (n_dev a power of two) the witness map becomes four-step NTTs whose two
+ * all-to-all transposes are hipMemcpyPeerAsync pushes over xGMI, one copy stream per peer link;
+ * the 1 KiB partial records are peer-copied to device_ids[0] and summed there.  The returned ctx is
+ * used like a single-device one: g16_prove / g16_prove_dev (w_dev on device_ids[0]) shard
+ * transparently, nothing of a proof touches the host between the witness upload and the 256-byte
+ * download.  Replaces the same reference call as g16_ctx_create + g16_prove
+ * (benches/groth16.rs:52-60); a Rust caller needs no launcher and no collective library.
+ * opt->device / rank / world / dist_wm are ignored (dist_wm < 0 forces a replicated witness map).
+ * device_ids may repeat an ordinal (several ranks time-sharing one GPU: functional tests).         */
+g16_status g16_ctx_create_multi(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
+                                uint32_t num_constraints, const int* device_ids, int n_dev,
+                                const g16_options* opt, g16_ctx** out);
+
 /* CircomReduction::witness_map_from_matrices (src/circom/qap.rs:23-88).
  * w: full_assignment, n_vars x 4 u64; h_out: domain_size x 4 u64 (natural order, Montgomery).   */
 g16_status g16_witness_map(g16_ctx* ctx, const uint64_t* w, size_t n_vars, uint64_t* h_out);
@@ -138,6 +153,20 @@ g16_status g16_prove_partial_dev(g16_ctx* ctx, const uint64_t r[4], const uint64
 g16_status g16_prove_finish(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4],
                             const uint8_t* partials, int world, uint8_t proof_out[G16_PROOF_BYTES]);
 
+/* Device-side hand-offs for host frameworks that own a stream (one process per GPU, torch / RCCL):
+ * after g16_dist_set_exchange_stream(ctx, hipStream_t, 1) the phase calls below never block the
+ * host -- the registered stream is made to wait (hipStreamWaitEvent) for each send buffer / partial
+ * record, and every phase waits for what the caller has enqueued on that stream so far (its
+ * all-to-all / all-gather).  g16_partial_buffer(): this rank's record in HBM (G16_PARTIAL_BYTES),
+ * the all-gather's input; g16_gather_buffer(): world x G16_PARTIAL_BYTES, its output;
+ * g16_prove_finish_dev() consumes the latter in place.  Without a registered stream the calls
+ * block until their output is complete (frameworks that cannot share a stream).                    */
+g16_status g16_dist_set_exchange_stream(g16_ctx* ctx, void* hip_stream, int enabled);
+void* g16_partial_buffer(g16_ctx* ctx);
+void* g16_gather_buffer(g16_ctx* ctx);
+g16_status g16_prove_finish_dev(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4],
+                                uint8_t proof_out[G16_PROOF_BYTES]);
+
 /* Fully sharded prover (ctx created with options.dist_wm = 1, world a power of two): the witness map
  * (CircomReduction::witness_map_from_matrices, src/circom/qap.rs:23-88) is split over the ranks as
  * four-step NTTs whose two transposes are all-to-all exchanges the host framework performs
@@ -150,6 +179,8 @@ size_t g16_dist_exchange_bytes(const g16_ctx* ctx);
 g16_status g16_prove_dist_phase1(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4],
                                  const void* w_dev, size_t n_vars, void* send_dev);
 g16_status g16_prove_dist_phase2(g16_ctx* ctx, const void* recv_dev, void* send_dev);
+/* partial_out may be NULL when an exchange stream is registered: the record then stays in
+ * g16_partial_buffer() and the registered stream waits for it.                                     */
 g16_status g16_prove_dist_phase3(g16_ctx* ctx, const void* recv_dev,
                                  uint8_t partial_out[G16_PARTIAL_BYTES]);
 
@@ -160,10 +191,14 @@ g16_status g16_set_profiling(g16_ctx* ctx, int enabled);
 g16_status g16_stage_times(g16_ctx* ctx, float ms[G16_N_STAGES], uint32_t launches[G16_N_STAGES]);
 const char* g16_stage_name(int stage);
 /* sizes chosen at create time: out[0]=c_w out[1]=W_w out[2]=planes_w out[3]=D_w, [4..7] same for H,
- * out[8] = domain_size, out[9] = log2(domain_size)                                               */
+ * out[8] = domain_size, out[9] = log2(domain_size), out[10] / out[11] = points of the witness / H
+ * shard (rank 0's for a multi-device ctx), out[12] = devices                                     */
 g16_status g16_ctx_info(const g16_ctx* ctx, uint32_t out[16]);
 /* device pointer of the ctx's witness staging buffer (n_vars x 32 bytes) for g16_prove_dev        */
 void* g16_witness_buffer(g16_ctx* ctx);
+/* page-locked HOST staging buffer (n_vars x 32 bytes, owned by the ctx): a caller that writes the
+ * full assignment here (instead of into a Vec) gets the H2D copy of g16_prove at PCIe line rate   */
+void* g16_witness_host_buffer(g16_ctx* ctx);
 
 /* Constraint satisfaction of a witness: (A_i . w)(B_i . w) == C_i . w for every row, the check
  * CircomBuilder::build performs in debug builds (reference src/circom/builder.rs:101-114; the

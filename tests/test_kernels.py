@@ -231,16 +231,26 @@ def test_constraint_satisfaction_kernel(lib, golden):
     CircomBuilder::build (src/circom/builder.rs:101-114), on the reference's own fixtures"""
     import circom_compat_amd as cc
     import json
-    r1 = cc.R1CS.from_file(os.path.join(golden, "mycircuit.r1cs"), lib)
-    assert cc.CircomCircuit(r1, [1, 33, 3, 11]).first_unsatisfied(lib) == -1
-    assert cc.CircomCircuit(r1, [1, 34, 3, 11]).first_unsatisfied(lib) == 0
-    r2 = cc.R1CS.from_file(os.path.join(golden, "circuit2.r1cs"), lib)
+    # circuits come from the builder, as in the reference's test: wire mapping disabled (builder.rs:84-85)
+    b1 = cc.CircomBuilder(cc.R1CS.from_file(os.path.join(golden, "mycircuit.r1cs"), lib))
+    assert b1.build([1, 33, 3, 11]).first_unsatisfied(lib) == -1
+    assert b1.build([1, 34, 3, 11]).first_unsatisfied(lib) == 0
+    with pytest.raises(cc.G16Error):
+        b1.build([1, 34, 3, 11], sanity_check=True, lib=lib)
+    # a circuit that keeps R1CS::from's mapping reads w[m[i]] (circuit.rs:35-58): mycircuit's labels
+    # permute the wires, so the wire-order witness no longer satisfies it and the public input moves
+    raw = cc.CircomCircuit(b1.r1cs, [1, 33, 3, 11])
+    m = b1.r1cs.wire_mapping
+    assert raw.full_assignment() == [[1, 33, 3, 11][m[i]] for i in range(4)]
+    assert raw.get_public_inputs() == [[1, 33, 3, 11][m[1]]]
+    assert b1.setup().r1cs.wire_mapping is None and b1.r1cs.wire_mapping is not None
+    b2 = cc.CircomBuilder(cc.R1CS.from_file(os.path.join(golden, "circuit2.r1cs"), lib))
     w2 = [int(x) for x in json.load(open(os.path.join(golden, "safe-circuit-witness.json")))]
-    c2 = cc.CircomCircuit(r2, w2)
+    c2 = b2.build(w2)
     assert c2.is_satisfied(lib)
     w_bad = list(w2)
     w_bad[70] = (w_bad[70] + 1) % o.R_MOD
-    bad = cc.CircomCircuit(r2, w_bad).first_unsatisfied(lib)
+    bad = b2.build(w_bad).first_unsatisfied(lib)
     # the oracle names the same first failing row
     cons = o.read_r1cs(open(os.path.join(golden, "circuit2.r1cs"), "rb").read())["constraints"]
     lc = lambda terms: sum(c * w_bad[j] for j, c in terms) % o.R_MOD
@@ -401,3 +411,109 @@ def test_error_paths_through_the_abi(lib, golden):
         pr.msm_g1(0, [1] * 10)
     # and the prover still works after the failed calls
     assert len(pr.prove(1, 2, [1, 33, 3, 11]).raw) == 256
+
+
+@pytest.mark.parametrize("logm,devices", [(4, [0, 0]), (6, [0, 0, 0, 0]), (5, [0, 0, 0])])
+def test_in_library_multi_device_prover(lib, logm, devices):
+    """g16_ctx_create_multi: one ctx, the ranks (point-range MSM shards + distributed witness map for
+    power-of-two device counts, replicated witness map otherwise) and BOTH all-to-all exchanges and
+    the gather live inside the library -- no host framework, no collective library.  Every listed
+    device is ordinal 0 here (ranks time-sharing one device); the proof must equal the oracle's, and
+    two consecutive proofs with different (r, s) cover buffer / event reuse."""
+    import circom_compat_amd as cc
+    cons, w, n_vars, n_pub = H.squaring_chain(logm)
+    rng = random.Random(logm)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    opk = o.trapdoor_setup(cons, n_vars, n_pub, *tox)
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, lib)
+    pk = H.pk_from_oracle(opk)
+    pr = cc.Prover(pk, mats, lib=lib, devices=devices)
+    assert pr.info()["devices"] == len(devices)
+    for _ in range(2):
+        r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+        want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2, len(cons), w)
+        assert pr.prove(r, s, w).raw == o.proof_to_bytes(want)
+    assert o.verify_proof(opk, w[1:2], want)
+    # device-resident witness (peer-broadcast from the first device): same bytes
+    wm = H.fr_mont_arr(w)
+    if lib.path.endswith("libg16_emu.so"):
+        ptr, keep = wm.ctypes.data, wm          # the emulator's device memory is host memory
+    else:
+        import torch
+        keep = torch.from_numpy(wm.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        ptr = keep.data_ptr()
+    assert pr.prove_dev(r, s, ptr).raw == o.proof_to_bytes(want)
+    # the sharded ctx proves only
+    with pytest.raises(cc.G16Error):
+        pr.witness_map(w)
+    with pytest.raises(cc.G16Error):
+        pr.prove(1, 2, w[:-1])
+    pr.close()
+
+
+def test_groth16_prove_surface_and_wire_mapping(lib, golden):
+    """SNARK::prove(&pk, circuit, rng) (reference src/zkey.rs:866, tests/groth16.rs:31): r, s from
+    the rng, circuit from the builder (wire mapping disabled, builder.rs:84-85) -> the proof
+    verifies for get_public_inputs(); same seed -> same (r, s) -> same bytes as the matrices entry."""
+    import circom_compat_amd as cc
+    pk, mats = cc.read_zkey(os.path.join(golden, "test.zkey"), lib)
+    opk, _ = o.read_zkey(open(os.path.join(golden, "test.zkey"), "rb").read())
+    builder = cc.CircomBuilder(cc.R1CS.from_file(os.path.join(golden, "mycircuit.r1cs"), lib))
+    circuit = builder.build([1, 33, 3, 11])
+    proof = cc.Groth16.prove(pk, mats, circuit, random.Random(7), lib=lib)
+    pub = circuit.get_public_inputs()
+    assert pub == [33]
+    assert o.verify_proof(opk, pub, H.proof_from_bytes(proof.raw))
+    assert not o.verify_proof(opk, [34], H.proof_from_bytes(proof.raw))
+    rng = random.Random(7)
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    same = cc.Groth16.create_proof_with_reduction_and_matrices(pk, r, s, mats, 2, 1, [1, 33, 3, 11], lib=lib)
+    assert same.raw == proof.raw
+    # a circuit that keeps a (non-identity) wire mapping is proved over w[m[i]] (circuit.rs:35-58),
+    # consistently with its own get_public_inputs(): a label-ordered witness through the mapping
+    # gives the same assignment, hence the same bytes; the wire-order witness through it does not
+    import copy
+    r1 = copy.copy(builder.r1cs)
+    r1.wire_mapping = [0, 3, 1, 2]
+    mapped = cc.CircomCircuit(r1, [1, 3, 11, 33])          # w'[m[i]] = w[i]
+    assert mapped.full_assignment() == [1, 33, 3, 11] and mapped.get_public_inputs() == [33]
+    assert mapped.first_unsatisfied(lib) == -1
+    assert cc.Groth16.prove(pk, mats, mapped, random.Random(7), lib=lib).raw == proof.raw
+    wrong = cc.CircomCircuit(r1, [1, 33, 3, 11])
+    assert wrong.first_unsatisfied(lib) == 0
+    assert cc.Groth16.prove(pk, mats, wrong, random.Random(7), lib=lib).raw != proof.raw
+
+
+def test_domain_too_large_and_bad_matrices(lib):
+    """SynthesisError::PolynomialDegreeTooLarge (reference src/circom/qap.rs:31,66: both the size-n
+    and the size-2n domain must exist, Fr two-adicity 28) surfaces as G16_ERR_DOMAIN_TOO_LARGE;
+    out-of-range wire indices / inconsistent row pointers are rejected at create time (the
+    reference panics on the out-of-bounds index)."""
+    import circom_compat_amd as cc
+    from circom_compat_amd import _binding as B
+    one = cc.fr_from_ints([1], lib)
+    m = (1 << 28) - 1                                   # m + num_inputs > 2^27: no 2n domain
+    # zero-copy all-zero row pointers: the domain check fires before anything is uploaded
+    rp = np.zeros(m + 1, dtype=np.uint32)
+    empty = cc.Csr.__new__(cc.Csr)
+    empty.row_ptr, empty.col, empty.coeff = rp, np.zeros(0, np.uint32), np.zeros((0, 4), np.uint64)
+    mats = cc.ConstraintMatrices(2, 3, m, empty, empty)
+    with pytest.raises(cc.SynthesisError) as e:
+        cc.Prover(None, mats, lib=lib, n_vars=4)
+    assert e.value.status == B.G16_ERR_DOMAIN_TOO_LARGE
+    # wire index beyond the witness
+    bad = cc.Csr([0, 1], [7], one)
+    ok = cc.Csr([0, 1], [1], one)
+    with pytest.raises(cc.G16Error) as e:
+        cc.Prover(None, cc.ConstraintMatrices(2, 2, 1, bad, ok), lib=lib, n_vars=4)
+    assert "wire index" in str(e.value)
+    # row_ptr that does not end at nnz
+    broken = cc.Csr.__new__(cc.Csr)
+    broken.row_ptr, broken.col, broken.coeff = np.array([0, 2], np.uint32), np.array([1], np.uint32), one
+    with pytest.raises(cc.G16Error) as e:
+        cc.Prover(None, cc.ConstraintMatrices(2, 2, 1, broken, ok), lib=lib, n_vars=4)
+    assert "row_ptr" in str(e.value)
+    with pytest.raises(cc.G16Error):
+        cc.Prover(None, cc.ConstraintMatrices(2, 2, 1, ok, ok), lib=lib)     # n_vars is required
