@@ -5,16 +5,34 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one full proof (CircomReduction witness map + 4 G1 MSMs + 1 G2 MSM + finalisation) of the
-synthetic squaring-chain circuit of SURVEY.md section 8(d) with m = 2^k - 2 constraints (default
-k = 22, BASELINE.json configs[2]); the proving key is a real trapdoor key minted on the GPU, the
-witness is resident in HBM when the timed region starts, every rank holds its point-range shard.
-N > 1: the MSMs are sharded by point range, the five partial sums are all-gathered over RCCL and
-combined locally ("all-reduce" of EC points), i.e. strong scaling of ONE proof.
+A step = one full proof (CircomReduction witness map + 4 G1 MSMs + 1 G2 MSM + finalisation) through
+the C ABI (Groth16::create_proof_with_reduction_and_matrices, reference benches/groth16.rs:52-60).
+Default workload = BASELINE.json configs[2]: the synthetic squaring-chain circuit of SURVEY.md
+section 8(d) with m = 2^22 - 2 constraints, a real trapdoor key minted on the GPU.
+
+`value` follows the bench contract: the witness is resident in HBM when the timed region starts.
+The SURVEY 8(d) step (host witness -> H2D -> ... -> 256 B D2H, witness in the ctx's page-locked
+staging buffer) is timed right after it and reported as `value_pcie_inclusive`.
+
+N > 1 (strong scaling of ONE proof): MSMs sharded by point range, witness map distributed
+(four-step NTTs, two all-to-all exchanges), 1 KiB partial records gathered and summed.
+  mode "in-library"  (default when this process can see N devices): rank 0 drives all N GPUs through
+                     ONE g16_ctx_create_multi ctx -- exchanges are peer copies over xGMI inside the
+                     library, no Python between phases; the other ranks only keep the barriers;
+  mode "ranks"       (G16_BENCH_MODE=ranks, or fewer visible devices than ranks): one ctx per
+                     process, RCCL all_to_all / all_gather on a torch stream the library orders
+                     itself against with events (g16_dist_set_exchange_stream): no host syncs.
+
+Other workloads / modes (BASELINE configs 2 and 5, the reference's own bench circuit):
+  --workload dense-skewed   3-term A rows / 2-term B rows, >= 50 % of the witness in {0, 1}, key
+                            written and re-read through the snarkjs .zkey format (read_zkey path)
+  --workload complex-circuit  tests/golden/complex-circuit-10000-10000.r1cs (benches/groth16.rs:87-108)
+  --mode parts              witness map and each MSM timed separately (device-resident operands)
 
 Rank 0 prints ONE JSON line: metric/value/unit/... plus `roofline` (dominant kernel, live HIP-event
 timing on the kernel's own stream), `cpu_baseline` (the oracle's multithreaded C restatement of the
-reference's CPU prover timed on this box's host cores on a bounded sample) and `parity`.
+reference's CPU prover timed on this box's host cores on the SAME inputs when it fits the time
+bound) and `parity`.
 """
 import argparse
 import json
@@ -32,6 +50,9 @@ R_MOD = 218882428718392752222464057452572750885483644004160343436982041865758084
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+# ------------------------------------------------------------------------------------------------
+# workloads (synthetic data; no oracle involved)
+# ------------------------------------------------------------------------------------------------
 def chain_circuit(cc, k):
     """squaring chain: wires [1, out, x0, x1, ...]; row i: (-x_i) * (x_i) = (-x_{i+1})"""
     m = (1 << k) - 2
@@ -53,13 +74,126 @@ def chain_circuit(cc, k):
     return mats, (A, B, Cm), w, n_vars
 
 
+def dense_skewed_circuit(cc, k, seed=5, n_bits=4096):
+    """SURVEY 8(d) config-5 substitute (the shape of circuit2.r1cs: ~3 / ~2 nnz per row): m = 2^k - 2
+    rows, row i defines a fresh wire out_i = (A_i.w)(B_i.w).  ~60 % of the rows are bit logic
+    ((b_i + b_j - b_k) * b or (..) * (1 - b): results in {0, 1, 2, -1}), the rest mix arbitrary
+    earlier wires with small +- coefficients, so that >= 50 % of the witness is in {0, 1} and the
+    rest is spread from tiny to uniform 254-bit values -- hot MSM buckets, as circom witnesses have."""
+    rng = random.Random(seed)
+    m = (1 << k) - 2
+    w = [1, 0] + [rng.randrange(2) for _ in range(n_bits)]
+    bits = list(range(2, 2 + n_bits))
+    coeffs = [1, R_MOD - 1, 2, R_MOD - 2, 3]
+    a_rp, b_rp, c_rp = [0], [0], [0]
+    a_col, a_val, b_col, b_val, c_col = [], [], [], [], []
+    for i in range(m - 1):
+        hi = len(w)
+        if rng.random() < 0.6:
+            ta = [(rng.choice(bits), 1), (rng.choice(bits), 1), (rng.choice(bits), R_MOD - 1)]
+            tb = [(rng.choice(bits), 1)] if rng.random() < 0.5 else [(0, 1), (rng.choice(bits), R_MOD - 1)]
+        else:
+            ta = [(rng.randrange(2, hi), rng.choice(coeffs)) for _ in range(3)]
+            tb = [(rng.randrange(2, hi), rng.choice(coeffs)) for _ in range(2)]
+        va = sum(c * w[j] for j, c in ta) % R_MOD
+        vb = sum(c * w[j] for j, c in tb) % R_MOD
+        val = va * vb % R_MOD
+        w.append(val)
+        if val in (0, 1):
+            bits.append(hi)
+        for j, c in ta:
+            a_col.append(j)
+            a_val.append(c)
+        for j, c in tb:
+            b_col.append(j)
+            b_val.append(c)
+        c_col.append(hi)
+        a_rp.append(len(a_col))
+        b_rp.append(len(b_col))
+        c_rp.append(len(c_col))
+    # last row: the public output copies the last wire
+    w[1] = w[-1]
+    a_col.append(len(w) - 1)
+    a_val.append(1)
+    b_col.append(0)
+    b_val.append(1)
+    c_col.append(1)
+    a_rp.append(len(a_col))
+    b_rp.append(len(b_col))
+    c_rp.append(len(c_col))
+    n_vars = len(w)
+    one = cc.fr_from_ints([1])
+    A = cc.Csr(a_rp, a_col, cc.fr_from_ints(a_val))
+    B = cc.Csr(b_rp, b_col, cc.fr_from_ints(b_val))
+    Cm = cc.Csr(c_rp, c_col, np.tile(one, (len(c_col), 1)))
+    mats = cc.ConstraintMatrices(2, n_vars - 1, m, A, B)
+    return mats, (A, B, Cm), w, n_vars
+
+
+def solve_r1cs_forward(r1cs, known):
+    """witness of a circuit whose rows each define ONE new wire linearly in C (what circom emits
+    for `x <== a*b`): propagate (A.w)(B.w) = C.w row by row.  Stands in for the WASM witness
+    calculator (out of scope) on the reference's bench circuit."""
+    import circom_compat_amd as cc
+    n = r1cs.num_variables
+    w = [None] * n
+    for i, v in known.items():
+        w[i] = v % R_MOD
+    mats = []
+    for m in (r1cs.a, r1cs.b, r1cs.c):
+        mats.append((m.row_ptr.tolist(), m.col.tolist(), cc.fr_to_ints(m.coeff)))
+
+    def lc(M, i):
+        rp, col, val = M
+        acc, unk = 0, None
+        for j in range(rp[i], rp[i + 1]):
+            x = w[col[j]]
+            if x is None:
+                if unk is not None:
+                    return None, None, None
+                unk = (col[j], val[j])
+            else:
+                acc = (acc + val[j] * x) % R_MOD
+        return acc, unk, True
+
+    for i in range(r1cs.num_constraints):
+        a, ua, _ = lc(mats[0], i)
+        b, ub, _ = lc(mats[1], i)
+        c, uc, ok = lc(mats[2], i)
+        if a is None or b is None or ua or ub or not ok:
+            raise ValueError(f"row {i}: A or B has an unknown wire")
+        if uc is None:
+            if a * b % R_MOD != c:
+                raise ValueError(f"row {i} is not satisfied")
+            continue
+        wire, cf = uc
+        w[wire] = (a * b - c) * pow(cf, R_MOD - 2, R_MOD) % R_MOD
+    if any(x is None for x in w):
+        raise ValueError("unsolved wires remain")
+    return w
+
+
+def complex_circuit(cc):
+    """the reference bench's default circuit (benches/groth16.rs:87-108), input a = 3"""
+    r1cs = cc.R1CS.from_file(os.path.join(ROOT, "tests", "golden", "complex-circuit-10000-10000.r1cs"))
+    # circom wire order: 0 = one, 1 = output c, 2 = private input a, 3.. = b[]
+    w = solve_r1cs_forward(r1cs, {0: 1, 2: 3})
+    mats = r1cs.matrices()
+    return mats, (r1cs.a, r1cs.b, r1cs.c), w, r1cs.num_variables
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2", type=int, default=22, help="log2 of the domain (m = 2^k - 2 constraints)")
-    ap.add_argument("--cpu-log2", type=int, default=17, help="size of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--workload", choices=["chain", "dense-skewed", "complex-circuit"], default="chain")
+    ap.add_argument("--mode", choices=["prove", "parts"], default="prove")
+    ap.add_argument("--cpu-log2", type=int, default=17, help="probe size of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-budget", type=float, default=60.0,
+                    help="seconds of CPU work the baseline sample may take")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--planes", type=int, default=0)
     args = ap.parse_args()
@@ -68,122 +202,212 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    n_gpus = max(args.gpus, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    visible = torch.cuda.device_count()
     # G16_BENCH_BACKEND=gloo G16_BENCH_DEVICE=0: run the N > 1 code path with every rank on ONE GPU
-    # and the exchanges staged through the host -- a functional check of this script on a 1-GPU box,
-    # never a measurement
+    # -- a functional check of this script on a 1-GPU box, never a measurement
     backend = os.environ.get("G16_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = int(os.environ.get("G16_BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(local_rank)
+    one_gpu = backend != "nccl"
+    mode = os.environ.get("G16_BENCH_MODE", "")
+    if n_gpus == 1:
+        mode = "single"
+    elif not mode:
+        mode = "inlib" if (visible >= n_gpus or one_gpu or world == 1) else "ranks"
+    if mode == "ranks" and world != n_gpus:
+        raise SystemExit("mode 'ranks' needs torch.distributed.run with one process per GPU")
+    if one_gpu:
+        local_rank = int(os.environ.get("G16_BENCH_DEVICE", 0))
+    active = mode != "inlib" or rank == 0     # ranks that prove (idle ranks never touch a GPU)
+    if active:
+        torch.cuda.set_device(local_rank if mode != "inlib" else (0 if not one_gpu else local_rank))
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
+        if mode == "ranks" and backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:  # in-library mode: the idle ranks only keep the barriers -- on the CPU, off the GPUs
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import circom_compat_amd as cc
+    from circom_compat_amd import _binding
+    lib_path = _binding.load().path
+    if os.environ.get("G16_AMD_LIB"):
+        if "emu" in os.path.basename(lib_path):
+            raise SystemExit("G16_AMD_LIB points at the emulator build: not a measurement")
+        print(f"bench.py: product library overridden by G16_AMD_LIB={lib_path}", file=sys.stderr)
+    if args.mode == "parts":
+        os.environ["G16_NO_OVERLAP"] = "1"    # one stream: every stage timer is an uncontended time
+
     k = args.log2
     t_setup = time.time()
-    mats, (A, B, Cm), w_ints, n_vars = chain_circuit(cc, k)
+    zkey_path = None
+    if args.workload == "chain":
+        mats, (A, B, Cm), w_ints, n_vars = chain_circuit(cc, k)
+        desc = f"synthetic squaring-chain R1CS, 2^{k}-2 constraints"
+    elif args.workload == "dense-skewed":
+        mats, (A, B, Cm), w_ints, n_vars = dense_skewed_circuit(cc, k)
+        desc = (f"synthetic dense-rows R1CS (3-term A / 2-term B rows), 2^{k}-2 constraints, skewed witness, "
+                "key through the snarkjs .zkey writer + read_zkey")
+    else:
+        mats, (A, B, Cm), w_ints, n_vars = complex_circuit(cc)
+        k = (mats.num_constraints + 2 - 1).bit_length()
+        desc = "complex-circuit-10000-10000.r1cs (the reference bench's circuit, benches/groth16.rs:87-108), a = 3"
     m = mats.num_constraints
+    frac01 = sum(1 for x in w_ints if x in (0, 1)) / len(w_ints)
     rng = random.Random(k)
     tox = [rng.randrange(1, R_MOD) for _ in range(5)]
-    pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox, device=local_rank)
-    dist_wm = world > 1 and os.environ.get("G16_BENCH_DIST_WM", "1") != "0"
-    prover = cc.Prover(pk, mats, device=local_rank, rank=rank, world=world,
-                       window_bits=args.window_bits, planes=args.planes, dist_wm=dist_wm)
-    w = cc.fr_from_ints(w_ints)
     rs_rng = random.Random(1000 + k)
     r, s = rs_rng.randrange(R_MOD), rs_rng.randrange(R_MOD)
     rs = cc.fr_from_ints([r, s])
-    # witness resident in HBM before the timed region (torch owns the buffer: plumbing only)
-    w_dev = torch.from_numpy(w.view(np.int64)).to(f"cuda:{local_rank}")
-    torch.cuda.synchronize()
+    w = cc.fr_from_ints(w_ints)
+
+    pk = prover = None
+    if active:
+        dev0 = local_rank if mode != "inlib" else (local_rank if one_gpu else 0)
+        pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox, device=dev0)
+        if args.workload != "chain":
+            # through the file format: snarkjs-layout .zkey written, mapped and parsed back (read_zkey)
+            import tempfile
+            zkey_path = os.path.join(tempfile.gettempdir(), f"g16_bench_{os.getpid()}.zkey")
+            cc.write_zkey(zkey_path, pk, mats)
+            pk, mats = cc.read_zkey(zkey_path)
+            m = mats.num_constraints
+        kw = dict(window_bits=args.window_bits, planes=args.planes)
+        if mode == "single":
+            prover = cc.Prover(pk, mats, device=local_rank, **kw)
+        elif mode == "inlib":
+            devices = [dev0] * n_gpus if one_gpu else list(range(n_gpus))
+            prover = cc.Prover(pk, mats, devices=devices, **kw)
+        else:
+            dist_wm = os.environ.get("G16_BENCH_DIST_WM", "1") != "0"
+            prover = cc.Prover(pk, mats, device=local_rank, rank=rank, world=world, dist_wm=dist_wm, **kw)
+    dev = f"cuda:{torch.cuda.current_device()}" if active else "cpu"
+    w_dev = torch.from_numpy(w.view(np.int64)).to(dev) if active else None
+    if active:
+        torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
-    dev = f"cuda:{local_rank}"
-    gathered = torch.empty(world * 1024, dtype=torch.uint8, device=dev) if world > 1 else None
-    if dist_wm:
-        nbytes = prover.exchange_bytes()
-        send = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        recv = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    # ---- per-rank path: RCCL collectives on a torch stream the library orders itself against
+    if mode == "ranks":
+        xs = torch.cuda.Stream()
+        prover.set_exchange_stream(xs.cuda_stream)
+        dist_wm = prover.dist_wm
+        if dist_wm:
+            nbytes = prover.exchange_bytes()
+            send = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            recv = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        part_t = cc.device_tensor(prover.partial_buffer(), 1024, dev)
+        gath_t = cc.device_tensor(prover.gather_buffer(), world * 1024, dev)
 
-    def exchange():
-        # RCCL all-to-all over xGMI on torch's stream; only that stream is waited for, so the ctx's
-        # own MSM stream keeps running underneath
-        if backend == "nccl":
-            dist.all_to_all_single(recv, send)
-            torch.cuda.current_stream().synchronize()
-        else:
-            hs, hr = send.cpu(), torch.empty(nbytes, dtype=torch.uint8)
-            dist.all_to_all_single(hr, hs)
-            recv.copy_(hr)
-            torch.cuda.current_stream().synchronize()
+        def exchange():
+            with torch.cuda.stream(xs):
+                if backend == "nccl":
+                    dist.all_to_all_single(recv, send)
+                else:
+                    xs.synchronize()
+                    hs, hr = send.cpu(), torch.empty(nbytes, dtype=torch.uint8)
+                    dist.all_to_all_single(hr, hs)
+                    recv.copy_(hr)
+
+        def gather():
+            with torch.cuda.stream(xs):
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(gath_t, part_t)
+                else:
+                    xs.synchronize()
+                    parts = [torch.empty(1024, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(parts, part_t.cpu())
+                    gath_t.copy_(torch.cat(parts))
 
     def step():
-        if world == 1:
+        if mode in ("single", "inlib"):
             return prover.prove_dev(rs[0], rs[1], w_dev.data_ptr())
         if dist_wm:
             prover.dist_phase1(rs[0], rs[1], w_dev.data_ptr(), send.data_ptr())
             exchange()
             prover.dist_phase2(recv.data_ptr(), send.data_ptr())
             exchange()
-            part = prover.dist_phase3(recv.data_ptr())
+            prover.dist_phase3_dev(recv.data_ptr())
         else:
-            part = prover.prove_partial(rs[0], rs[1], w_dev_ptr=w_dev.data_ptr())
-        if backend == "nccl":
-            mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
-            dist.all_gather_into_tensor(gathered, mine)
-            return prover.prove_finish(rs[0], rs[1], gathered.cpu().numpy().tobytes())
-        parts = [torch.empty(1024, dtype=torch.uint8) for _ in range(world)]
-        dist.all_gather(parts, torch.frombuffer(bytearray(part), dtype=torch.uint8))
-        return prover.prove_finish(rs[0], rs[1], b"".join(p.numpy().tobytes() for p in parts))
+            raise SystemExit("mode 'ranks' runs the fully sharded prover (G16_BENCH_DIST_WM=1)")
+        gather()
+        return prover.prove_finish_dev(rs[0], rs[1])
 
+    def barrier():
+        if dist:
+            dist.barrier()
+
+    proof = None
     for _ in range(args.warmup):
-        proof = step()
-    prover.set_profiling(True)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+        if active:
+            proof = step()
+    if active:
+        prover.set_profiling(True)
+    barrier()
+    if active:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        proof = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+        if active:
+            proof = step()
+    if active:
+        torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+                         device=dev if (mode == "ranks" and backend == "nccl") else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if not active or rank != 0:
+        if dist:
+            dist.barrier()          # rank 0's checker legs run while the others wait here
+            dist.destroy_process_group()
+        return
     stages = prover.stage_times()
     prover.set_profiling(False)
     info = prover.info()
-    # PCIe-inclusive variant (host witness -> H2D inside the call): reported beside, never as `value`
-    host_ms = None
-    if world == 1:
-        prover.prove(rs[0], rs[1], w)
-        t1 = time.perf_counter()
-        for _ in range(2):
-            prover.prove(rs[0], rs[1], w)
-        host_ms = (time.perf_counter() - t1) / 2 * 1e3
 
-    if rank != 0:
-        if dist:
-            dist.destroy_process_group()
-        return
+    # ---- the SURVEY 8(d) step: host witness (page-locked staging buffer of the ctx) -> H2D -> proof
+    host_ms = None
+    if mode in ("single", "inlib"):
+        host_w = prover.witness_host_buffer()
+        host_w[:] = w
+        prover.prove(rs[0], rs[1], host_w)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            p_host = prover.prove(rs[0], rs[1], host_w)
+        host_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        assert p_host.raw == proof.raw
+
+    # ---- config 2: the witness map and every MSM on their own (device-resident operands)
+    parts = None
+    if args.mode == "parts" and mode == "single":
+        h_dev = torch.empty((info["domain_size"], 4), dtype=torch.int64, device=dev)
+
+        def timed(fn, reps=3):
+            fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t1) / reps * 1e3
+
+        wptr = w_dev.data_ptr()
+        parts = {"witness_map_ms": timed(lambda: prover.witness_map_dev(wptr, h_dev.data_ptr())),
+                 "msm_A_ms": timed(lambda: prover.msm_g1_dev(0, wptr + 32, n_vars - 1)),
+                 "msm_B1_ms": timed(lambda: prover.msm_g1_dev(1, wptr + 32, n_vars - 1)),
+                 "msm_L_ms": timed(lambda: prover.msm_g1_dev(2, wptr + 64, n_vars - 2)),
+                 "msm_H_ms": timed(lambda: prover.msm_g1_dev(3, h_dev.data_ptr(), info["domain_size"])),
+                 "msm_B2_ms": timed(lambda: prover.msm_g2_dev(wptr + 32, n_vars - 1)),
+                 "note": "each MSM = its own digit sort + bucket accumulation + reduction + affine result; "
+                         "the full prove shares one sort among A, B1, L, B2 and overlaps the witness map"}
 
     # ---------------- parity (outside the timed region; oracle = checker only) ----------------
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -197,48 +421,63 @@ def main():
     rejected_wrong = not o.verify_proof(vk, [(w_ints[1] + 1) % R_MOD], H.proof_from_bytes(proof.raw))
     parity = {"proof_verifies": verified, "wrong_public_input_rejected": bool(rejected_wrong)}
 
-    # ---------------- CPU baseline: bounded sample on this box's host cores ----------------
-    # The sample size adapts to the box: a 2^cpu_log2 probe proof is timed first, then the largest
-    # circuit (<= the GPU's) whose two proofs fit in ~20 s of CPU work is timed and byte-compared.
+    # ---------------- CPU baseline: the SAME (pk, r, s, w) when it fits the time bound -----------
+    # A 2^cpu_log2 probe proof sizes the sample: the bench's own inputs are proved on the CPU (and
+    # byte-compared with the GPU proof) when one such proof is estimated to fit --cpu-budget seconds;
+    # otherwise the largest smaller chain circuit that does is timed and compared instead.
     cpu = None
     if args.cpu_log2 > 0:
         import cpu_ref
 
-        def cpu_case(kc, max_reps, budget_s):
+        def cpu_prove(pk_c, mats_c, wc, reps):
+            t_cpu, out = 0.0, None
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                out = cpu_ref.prove(pk_c, mats_c, rs[0:1].copy(), rs[1:2].copy(), wc)
+                t_cpu += time.perf_counter() - t1
+            return out, t_cpu
+
+        def small_case(kc):
             mats_c, (Ac, Bc, Cc), wc_ints, nvc = chain_circuit(cc, kc)
-            pk_c = cc.trapdoor_setup(Ac, Bc, Cc, nvc, 1, tox, device=local_rank)
+            pk_c = cc.trapdoor_setup(Ac, Bc, Cc, nvc, 1, tox, device=torch.cuda.current_device())
             wc = cc.fr_from_ints(wc_ints)
-            pr_c = cc.Prover(pk_c, mats_c, device=local_rank)
+            pr_c = cc.Prover(pk_c, mats_c, device=torch.cuda.current_device())
             gpu_small = pr_c.prove(rs[0], rs[1], wc)
             pr_c.close()
-            reps, t_cpu, same = 0, 0.0, True
-            while reps < 1 or (t_cpu < budget_s and reps < max_reps):
-                t1 = time.perf_counter()
-                cpu_proof = cpu_ref.prove(pk_c, mats_c, rs[0:1].copy(), rs[1:2].copy(), wc)
-                t_cpu += time.perf_counter() - t1
-                reps += 1
-                same = same and (cpu_proof == gpu_small.raw)
-            return mats_c.num_constraints, reps, t_cpu, same
+            return pk_c, mats_c, wc, gpu_small.raw
 
-        # N > 1: only the byte-comparison of a small single-GPU proof (the timed baseline belongs to
-        # the N = 1 line; torchrun also pins OMP_NUM_THREADS=1)
-        kc = min(args.cpu_log2, k) if world == 1 else min(args.cpu_log2, k, 14)
-        m_c, reps, t_cpu, same = cpu_case(kc, 1, 0.0)
-        parity["bit_identical_to_cpu_at_2^%d" % kc] = bool(same)
-        per_proof = t_cpu / reps
-        grow = 0
-        while world == 1 and kc + grow < min(k, 22) and per_proof * (2 ** (grow + 1)) * 2 <= 20.0:
-            grow += 1
-        if grow > 0:
-            kc += grow
-            m_c, reps, t_cpu, same = cpu_case(kc, 4, 12.0)
-            parity["bit_identical_to_cpu_at_2^%d" % kc] = bool(same)
-        cpu = None if world > 1 else {"value": m_c * reps / t_cpu, "unit": "constraints/s",
-               "cores": cpu_ref.max_threads(), "kind": "port",
-               "sample": f"{reps} proof(s) of the 2^{kc}-constraint squaring-chain circuit "
-                         f"({t_cpu:.1f} s of CPU work); C restatement of ark-groth16 0.5 prove() "
-                         "(arkworks itself is not buildable offline)",
-               "host_cpu_count": os.cpu_count()}
+        kp = min(args.cpu_log2, k)
+        pk_c, mats_c, wc, gpu_small = small_case(kp)
+        cpu_ref.prove(pk_c, mats_c, rs[0:1].copy(), rs[1:2].copy(), wc)      # thread pool warm-up
+        out, t_probe = cpu_prove(pk_c, mats_c, wc, 1)
+        parity["bit_identical_to_cpu_at_2^%d" % kp] = bool(out == gpu_small)
+        est_full = t_probe * (2 ** (k - kp)) * 1.15
+        if n_gpus > 1:
+            cpu = None      # the timed baseline belongs to the N = 1 line (torchrun pins OMP_NUM_THREADS=1)
+        elif est_full <= args.cpu_budget:
+            reps = 2 if est_full * 2 <= args.cpu_budget / 2 else 1
+            out, t_cpu = cpu_prove(pk, mats, w, reps)
+            parity["bit_identical_to_cpu_at_2^%d" % k] = bool(out == proof.raw)
+            sample = (f"{reps} proof(s) of the bench's own inputs: {desc} ({t_cpu:.1f} s of CPU work)")
+            cpu = {"value": m * reps / t_cpu, "unit": "constraints/s"}
+        else:
+            grow = 0
+            while kp + grow + 1 < k and t_probe * (2 ** (grow + 1)) * 1.15 <= args.cpu_budget:
+                grow += 1
+            kc = kp + grow
+            if grow:
+                pk_c, mats_c, wc, gpu_small = small_case(kc)
+            out, t_cpu = cpu_prove(pk_c, mats_c, wc, 1)
+            parity["bit_identical_to_cpu_at_2^%d" % kc] = bool(out == gpu_small)
+            sample = (f"1 proof of the 2^{kc}-constraint squaring-chain circuit ({t_cpu:.1f} s of CPU work; "
+                      f"the 2^{k} inputs were estimated at {est_full:.0f} s > --cpu-budget)")
+            cpu = {"value": mats_c.num_constraints / t_cpu, "unit": "constraints/s"}
+        if cpu:
+            cpu.update({"cores": cpu_ref.max_threads(), "kind": "port",
+                        "sample": sample + "; C restatement of ark-groth16 0.5 prove() built with "
+                                  + ("-O3 -mbmi2 -madx" if cpu_ref.variant() == "adx" else "-O3")
+                                  + " (arkworks itself is not buildable offline)",
+                        "host_cpu_count": os.cpu_count()})
 
     # ---------------- roofline of the dominant kernel (k_bucket_accumulate<Fq>) ----------------
     acc_ms, acc_cnt = stages["msm_accumulate_g1"]
@@ -250,7 +489,7 @@ def main():
     achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if world == 1 and os.path.exists(tpath):
+    if n_gpus == 1 and os.path.exists(tpath) and args.workload == "chain":
         t = json.load(open(tpath))
         if t.get("log2_domain") == k:
             traffic = t["traffic_bytes_per_launch"]
@@ -272,25 +511,43 @@ def main():
            "alu_only_ceiling_mixed_additions_per_s": 16.7e9}
 
     ms_per_step = elapsed / args.steps * 1e3
+    if mode == "single":
+        par = "single-gpu"
+    else:
+        par = (f"msm-point-range-shard x{n_gpus} + four-step witness map (2 all-to-all), "
+               + ("one g16_ctx_create_multi ctx in one process: peer copies over xGMI inside the library"
+                  if mode == "inlib" else "one process per GPU: RCCL all_to_all / all_gather, event hand-offs"))
+        if one_gpu:
+            par += " [functional run: every rank on ONE GPU]"
     out = {
         "metric": "Groth16 constraints/sec (BN254)", "value": m * args.steps / elapsed,
-        "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "unit": "constraints/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "int32x9 (29-bit limbs of 254-bit Montgomery integers)",
         "data": "synthetic",
-        "config": {"workload": f"synthetic squaring-chain R1CS, 2^{k}-2 constraints, BN254, full prove "
-                               "(witness map + 4 G1 MSM + 1 G2 MSM + finalize), trapdoor key minted on GPU",
+        "config": {"workload": f"{desc}, BN254, full prove (witness map + 4 G1 MSM + 1 G2 MSM + finalize), "
+                               "trapdoor key minted on GPU",
                    "log2_domain": k, "num_constraints": m, "n_vars": n_vars,
-                   "parallelism": (f"msm-point-range-shard x{world}" + (" + four-step witness map (2 all-to-all)" if dist_wm else " (witness map replicated)")) if world > 1 else "single-gpu",
-                   "msm": info},
+                   "witness_fraction_in_{0,1}": round(frac01, 4),
+                   "parallelism": par, "msm": info},
         "roofline": roofline, "alu": alu, "cpu_baseline": cpu, "parity": parity,
         "stages_ms_per_step": {n: ms / args.steps for n, (ms, _c) in stages.items()},
-        "setup_s": t_setup, "ms_per_step_with_host_witness_upload": host_ms,
+        "setup_s": t_setup,
+        "value_pcie_inclusive": (m / (host_ms * 1e-3)) if host_ms else None,
+        "ms_per_step_pcie_inclusive": host_ms,
+        "pcie_inclusive_note": "SURVEY 8(d) step: witness in the ctx's page-locked host buffer -> H2D -> ... "
+                               "-> 256 B D2H; `value` keeps the witness resident in HBM (bench contract)",
+        "library": lib_path,
     }
+    if parts:
+        out["parts_ms"] = parts
     if cpu:
         out["gpu_over_cpu"] = out["value"] / cpu["value"]
     print(json.dumps(out), flush=True)
+    if zkey_path and os.path.exists(zkey_path):
+        os.remove(zkey_path)
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

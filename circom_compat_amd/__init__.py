@@ -36,7 +36,7 @@ from ._binding import G16Error, SerializationError, SynthesisError  # noqa: F401
 __all__ = ["read_zkey", "R1CSFile", "R1CS", "CircomCircuit", "CircomBuilder", "CircomReduction", "LibsnarkReduction", "Groth16",
            "Prover", "ProvingKey", "VerifyingKey", "ConstraintMatrices", "Proof", "G16Error",
            "SynthesisError", "SerializationError", "fr_from_ints", "fr_to_ints", "read_wtns",
-           "trapdoor_setup", "Csr", "write_zkey"]
+           "trapdoor_setup", "Csr", "write_zkey", "device_tensor"]
 
 FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
@@ -69,6 +69,20 @@ def _as_fr(x, lib) -> np.ndarray:
     if isinstance(x, np.ndarray) and x.dtype == np.uint64:
         return np.ascontiguousarray(x).reshape(-1, 4)
     return fr_from_ints(list(x), lib)
+
+
+class _RawDeviceBytes:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr: int, nbytes: int, device=None):
+    """uint8 torch view of library-owned device memory (g16_partial_buffer / g16_gather_buffer), so
+    that a host framework can hand it to its collectives (RCCL all_gather) without a host copy.
+    Plumbing only: torch is imported here, never by the proving path."""
+    import torch
+    return torch.as_tensor(_RawDeviceBytes(ptr, nbytes), device=device or "cuda")
 
 
 class Csr:
@@ -446,6 +460,22 @@ class Prover:
         s = _as_fr(scalars, self.lib)
         out = np.empty(128, dtype=np.uint8)
         self.lib.check(self.lib.g16_msm_g2(self.ctx, _np_ptr(s), s.shape[0], _np_ptr(out)), self.ctx)
+        return out.tobytes()
+
+    def witness_map_dev(self, w_dev_ptr: int, h_dev_ptr: int):
+        self.lib.check(self.lib.g16_witness_map_dev(self.ctx, C.c_void_p(w_dev_ptr), self.n_vars,
+                                                    C.c_void_p(h_dev_ptr)), self.ctx)
+
+    def msm_g1_dev(self, which: int, scalars_dev_ptr: int, count: int) -> bytes:
+        out = np.empty(64, dtype=np.uint8)
+        self.lib.check(self.lib.g16_msm_g1_dev(self.ctx, which, C.c_void_p(scalars_dev_ptr), count,
+                                               _np_ptr(out)), self.ctx)
+        return out.tobytes()
+
+    def msm_g2_dev(self, scalars_dev_ptr: int, count: int) -> bytes:
+        out = np.empty(128, dtype=np.uint8)
+        self.lib.check(self.lib.g16_msm_g2_dev(self.ctx, C.c_void_p(scalars_dev_ptr), count,
+                                               _np_ptr(out)), self.ctx)
         return out.tobytes()
 
     def prove(self, r, s, full_assignment) -> Proof:

@@ -88,7 +88,8 @@ ABI_SYMBOLS = [
     "g16_prove_finish", "g16_dist_exchange_bytes", "g16_prove_dist_phase1", "g16_prove_dist_phase2",
     "g16_prove_dist_phase3", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info",
     "g16_witness_buffer", "g16_witness_host_buffer", "g16_ctx_create_multi", "g16_dist_set_exchange_stream",
-    "g16_partial_buffer", "g16_gather_buffer", "g16_prove_finish_dev", "g16_debug_ntt", "g16_debug_alu_bench", "g16_check_satisfied", "g16_zkey_write",
+    "g16_partial_buffer", "g16_gather_buffer", "g16_prove_finish_dev", "g16_witness_map_dev", "g16_msm_g1_dev",
+    "g16_msm_g2_dev", "g16_debug_ntt", "g16_debug_alu_bench", "g16_check_satisfied", "g16_zkey_write",
     "g16_setup_create", "g16_setup_create_ex", "g16_setup_destroy", "g16_setup_key",
     "g16_loader_last_error", "g16_zkey_open", "g16_zkey_open_mem", "g16_zkey_close",
     "g16_zkey_header_get", "g16_zkey_key", "g16_zkey_ic", "g16_zkey_matrices", "g16_r1cs_open",
@@ -143,6 +144,9 @@ class Library:
             "g16_ctx_info": (C.c_int, [vp, _u32p]),
             "g16_witness_buffer": (vp, [vp]),
             "g16_witness_host_buffer": (vp, [vp]),
+            "g16_witness_map_dev": (C.c_int, [vp, vp, C.c_size_t, vp]),
+            "g16_msm_g1_dev": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),
+            "g16_msm_g2_dev": (C.c_int, [vp, vp, C.c_size_t, vp]),
             "g16_ctx_create_multi": (C.c_int, [C.POINTER(KeyDesc), C.POINTER(Csr), C.POINTER(Csr), C.c_uint32,
                                                C.POINTER(C.c_int), C.c_int, C.POINTER(Options), C.POINTER(vp)]),
             "g16_dist_set_exchange_stream": (C.c_int, [vp, vp, C.c_int]),

@@ -529,8 +529,20 @@ g16_status g16_witness_map(g16_ctx* c, const uint64_t* w, size_t n_vars, uint64_
   });
 }
 
+g16_status g16_witness_map_dev(g16_ctx* c, const void* w_dev, size_t n_vars, void* h_dev_out) {
+  if (!c || !w_dev || !h_dev_out) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx proves only (g16_prove)");
+  if (c->dist_wm) return fail(c, G16_ERR_INVALID, "dist_wm ctx holds 1/world of the witness map");
+  if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+  return guarded(c, [&]() -> g16_status {
+    c->wm.run((const Fr*)w_dev, nullptr, (Fr*)h_dev_out, c->stream);
+    G16_HIP(hipStreamSynchronize(c->stream));
+    return G16_OK;
+  });
+}
+
 static g16_status msm_common(g16_ctx* c, int which, bool g2, const uint64_t* scalars, size_t len,
-                             uint8_t* out) {
+                             uint8_t* out, bool on_device = false) {
   if (!c || !scalars || !out) return fail(c, G16_ERR_INVALID, "null argument");
   if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx proves only (g16_prove)");
   if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
@@ -562,7 +574,8 @@ static g16_status msm_common(g16_ctx* c, int which, bool g2, const uint64_t* sca
       return fail(c, G16_ERR_INVALID, "unknown query id");
     }
     if (len > maxlen) return fail(c, G16_ERR_INVALID, "more scalars than resident points");
-    G16_HIP(hipMemcpyAsync(stage, scalars, len * 32, hipMemcpyHostToDevice, s));
+    if (on_device) stage = (Fr*)const_cast<uint64_t*>(scalars);
+    else G16_HIP(hipMemcpyAsync(stage, scalars, len * 32, hipMemcpyHostToDevice, s));
     sort->run(stage, (uint32_t)len, true, s);
     (void)idx_min;
     if (g2) {
@@ -584,6 +597,12 @@ g16_status g16_msm_g1(g16_ctx* c, int which, const uint64_t* scalars, size_t len
 }
 g16_status g16_msm_g2(g16_ctx* c, const uint64_t* scalars, size_t len, uint8_t out[128]) {
   return msm_common(c, 0, true, scalars, len, out);
+}
+g16_status g16_msm_g1_dev(g16_ctx* c, int which, const void* scalars_dev, size_t len, uint8_t out[64]) {
+  return msm_common(c, which, false, (const uint64_t*)scalars_dev, len, out, true);
+}
+g16_status g16_msm_g2_dev(g16_ctx* c, const void* scalars_dev, size_t len, uint8_t out[128]) {
+  return msm_common(c, 0, true, (const uint64_t*)scalars_dev, len, out, true);
 }
 
 g16_status g16_prove_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], const void* w_dev,

@@ -129,6 +129,11 @@ g16_status g16_witness_map(g16_ctx* ctx, const uint64_t* w, size_t n_vars, uint6
 g16_status g16_msm_g1(g16_ctx* ctx, int which, const uint64_t* scalars, size_t len, uint8_t out[64]);
 /* Same for b_g2_query[1 + i]; out: 128 bytes.                                                     */
 g16_status g16_msm_g2(g16_ctx* ctx, const uint64_t* scalars, size_t len, uint8_t out[128]);
+/* Device-resident variants (scalars / witness / h in HBM; BASELINE config 2 times the witness map
+ * and each MSM separately without PCIe in the way).  h_dev_out: domain_size x 32 bytes, Montgomery. */
+g16_status g16_witness_map_dev(g16_ctx* ctx, const void* w_dev, size_t n_vars, void* h_dev_out);
+g16_status g16_msm_g1_dev(g16_ctx* ctx, int which, const void* scalars_dev, size_t len, uint8_t out[64]);
+g16_status g16_msm_g2_dev(g16_ctx* ctx, const void* scalars_dev, size_t len, uint8_t out[128]);
 
 /* Groth16::<Bn254,CircomReduction>::create_proof_with_reduction_and_matrices
  * (benches/groth16.rs:52-60, src/zkey.rs:903-911) with pk/matrices/num_inputs/num_constraints

@@ -22,16 +22,37 @@ class _Key(C.Structure):
                 ("beta_g2", C.c_uint8 * 128), ("delta_g2", C.c_uint8 * 128)]
 
 
+VARIANT = None  # "adx" (built with -mbmi2 -madx) or "baseline": which build lib() loaded
+
+
+def _cpu_has_adx_bmi2():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = set(line.split(":", 1)[1].split())
+                return "adx" in flags and "bmi2" in flags
+    except OSError:
+        pass
+    return False
+
+
 def lib():
-    global _LIB
+    global _LIB, VARIANT
     if _LIB is None:
-        path = os.path.join(_HERE, "libg16_cpu_oracle.so")
+        VARIANT = "adx" if _cpu_has_adx_bmi2() and not os.environ.get("G16_CPU_BASELINE_ISA") else "baseline"
+        name = "libg16_cpu_oracle_adx.so" if VARIANT == "adx" else "libg16_cpu_oracle.so"
+        path = os.path.join(_HERE, name)
         if not os.path.exists(path):
             import subprocess
             subprocess.check_call(["make", "-C", _HERE])
         _LIB = C.CDLL(path)
         _LIB.g16cpu_max_threads.restype = C.c_int
     return _LIB
+
+
+def variant():
+    lib()
+    return VARIANT
 
 
 def set_threads(n):

@@ -1,0 +1,175 @@
+//! `GpuProver`: the device-resident `(ProvingKey<Bn254>, ConstraintMatrices<Fr>)` pair that
+//! `create_proof_with_reduction_and_matrices` borrows on every call in the reference
+//! (benches/groth16.rs:52-60, src/zkey.rs:903-911), uploaded and precomputed once.
+use std::ffi::CStr;
+use std::os::raw::c_int;
+
+use ark_bn254::{Bn254, Fr};
+use ark_groth16::{Proof, ProvingKey};
+use ark_relations::r1cs::{ConstraintMatrices, SynthesisError};
+use ark_std::rand::Rng;
+use ark_std::UniformRand;
+
+use crate::ffi;
+use crate::pack::{self, Csr};
+
+/// Which `R1CSToQAP` the key was generated for (README.md:69-74 of the reference: never mix them).
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum Reduction {
+    /// `ark_circom::CircomReduction`: snarkjs keys (`.zkey`)
+    Circom,
+    /// `ark_groth16::LibsnarkReduction`: keys from `Groth16::<Bn254>::generate_random_parameters_with_reduction`
+    Libsnark,
+}
+
+#[derive(Debug)]
+pub enum GpuError {
+    /// `SynthesisError::PolynomialDegreeTooLarge` and friends, as the CPU path reports them
+    Synthesis(SynthesisError),
+    /// anything else the library reports (status code, message)
+    Library(i32, String),
+}
+impl From<GpuError> for SynthesisError {
+    fn from(e: GpuError) -> Self {
+        match e {
+            GpuError::Synthesis(s) => s,
+            // the reference's signature only has SynthesisError: a device failure is "unexpected"
+            GpuError::Library(..) => SynthesisError::Unsatisfiable,
+        }
+    }
+}
+
+pub struct GpuProver {
+    ctx: *mut ffi::g16_ctx,
+    n_vars: usize,
+    num_inputs: usize,
+    num_constraints: usize,
+}
+// one proof in flight per ctx (the C ABI's contract); moving the handle between threads is fine
+unsafe impl Send for GpuProver {}
+
+fn last_error(ctx: *const ffi::g16_ctx) -> String {
+    unsafe { CStr::from_ptr(ffi::g16_last_error(ctx)).to_string_lossy().into_owned() }
+}
+fn check(ctx: *const ffi::g16_ctx, st: c_int) -> Result<(), GpuError> {
+    match st {
+        ffi::G16_OK => Ok(()),
+        ffi::G16_ERR_DOMAIN_TOO_LARGE => Err(GpuError::Synthesis(SynthesisError::PolynomialDegreeTooLarge)),
+        _ => Err(GpuError::Library(st, last_error(ctx))),
+    }
+}
+
+impl GpuProver {
+    /// The inputs `read_zkey` returns (src/zkey.rs:53-60), on one GPU.
+    pub fn new(pk: &ProvingKey<Bn254>, matrices: &ConstraintMatrices<Fr>) -> Result<Self, GpuError> {
+        Self::with_devices(pk, matrices, &[0], Reduction::Circom)
+    }
+
+    /// `devices.len() > 1`: ONE prover sharded over several GPUs inside the library
+    /// (`g16_ctx_create_multi`): point-range MSM shards, distributed witness map, peer copies
+    /// over xGMI.  The call surface does not change.
+    pub fn with_devices(
+        pk: &ProvingKey<Bn254>,
+        matrices: &ConstraintMatrices<Fr>,
+        devices: &[i32],
+        reduction: Reduction,
+    ) -> Result<Self, GpuError> {
+        let n_vars = pk.a_query.len();
+        let n_public = pk.vk.gamma_abc_g1.len() - 1;
+        let a = pack::pack_g1_vec(&pk.a_query);
+        let b1 = pack::pack_g1_vec(&pk.b_g1_query);
+        let b2 = pack::pack_g2_vec(&pk.b_g2_query);
+        let l = pack::pack_g1_vec(&pk.l_query);
+        // LibsnarkReduction's H query has domain_size - 1 points: pad with the point at infinity
+        let mut h = pack::pack_g1_vec(&pk.h_query);
+        let need = matrices.num_constraints + matrices.num_instance_variables;
+        let domain_size = need.next_power_of_two();
+        h.resize(64 * domain_size, 0);
+        let mut key = ffi::g16_key_desc {
+            n_vars: n_vars as u32,
+            n_public: n_public as u32,
+            domain_size: domain_size as u32,
+            a_query: a.as_ptr(),
+            b_g1_query: b1.as_ptr(),
+            b_g2_query: b2.as_ptr(),
+            l_query: l.as_ptr(),
+            h_query: h.as_ptr(),
+            alpha_g1: [0; 64],
+            beta_g1: [0; 64],
+            delta_g1: [0; 64],
+            beta_g2: [0; 128],
+            delta_g2: [0; 128],
+        };
+        pack::pack_g1(&pk.vk.alpha_g1, &mut key.alpha_g1);
+        pack::pack_g1(&pk.beta_g1, &mut key.beta_g1);
+        pack::pack_g1(&pk.delta_g1, &mut key.delta_g1);
+        pack::pack_g2(&pk.vk.beta_g2, &mut key.beta_g2);
+        pack::pack_g2(&pk.vk.delta_g2, &mut key.delta_g2);
+        let (ca, cb): (Csr, Csr) = pack::matrices_to_csr(matrices);
+        let (va, vb) = (ca.view(), cb.view());
+        let opt = ffi::g16_options {
+            reduction: if reduction == Reduction::Libsnark { ffi::G16_REDUCTION_LIBSNARK } else { ffi::G16_REDUCTION_CIRCOM },
+            ..Default::default()
+        };
+        let mut ctx: *mut ffi::g16_ctx = std::ptr::null_mut();
+        let ids: Vec<c_int> = devices.iter().map(|d| *d as c_int).collect();
+        let st = unsafe {
+            ffi::g16_ctx_create_multi(&key, &va, &vb, matrices.num_constraints as u32, ids.as_ptr(), ids.len() as c_int, &opt, &mut ctx)
+        };
+        check(std::ptr::null(), st)?;
+        Ok(GpuProver { ctx, n_vars, num_inputs: matrices.num_instance_variables, num_constraints: matrices.num_constraints })
+    }
+
+    pub fn num_inputs(&self) -> usize {
+        self.num_inputs
+    }
+    pub fn num_constraints(&self) -> usize {
+        self.num_constraints
+    }
+
+    /// `Groth16::<Bn254, CircomReduction>::create_proof_with_reduction_and_matrices` with
+    /// `(pk, matrices, num_inputs, num_constraints)` taken from `self`.
+    pub fn create_proof(&mut self, r: Fr, s: Fr, full_assignment: &[Fr]) -> Result<Proof<Bn254>, GpuError> {
+        if full_assignment.len() != self.n_vars {
+            return Err(GpuError::Synthesis(SynthesisError::MalformedVerifyingKey));
+        }
+        let mut raw = [0u8; ffi::G16_PROOF_BYTES];
+        let (rw, sw) = (pack::fr_words(&r), pack::fr_words(&s));
+        // the witness goes through the ctx's page-locked staging buffer: H2D at PCIe line rate
+        let st = unsafe {
+            let host = ffi::g16_witness_host_buffer(self.ctx) as *mut u64;
+            if host.is_null() {
+                let w = pack::fr_vec_words(full_assignment);
+                ffi::g16_prove(self.ctx, rw.as_ptr(), sw.as_ptr(), w.as_ptr(), self.n_vars, raw.as_mut_ptr())
+            } else {
+                pack::fr_write_words(full_assignment, std::slice::from_raw_parts_mut(host, 4 * self.n_vars));
+                ffi::g16_prove(self.ctx, rw.as_ptr(), sw.as_ptr(), host, self.n_vars, raw.as_mut_ptr())
+            }
+        };
+        check(self.ctx, st)?;
+        Ok(pack::unpack_proof(&raw))
+    }
+
+    /// `SNARK::prove(&pk, circuit, rng)` shape (src/zkey.rs:866): r, s from the rng.
+    pub fn prove_with_rng<R: Rng>(&mut self, full_assignment: &[Fr], rng: &mut R) -> Result<Proof<Bn254>, GpuError> {
+        let r = Fr::rand(rng);
+        let s = Fr::rand(rng);
+        self.create_proof(r, s, full_assignment)
+    }
+
+    /// `CircomReduction::witness_map_from_matrices` (src/circom/qap.rs:23-88) on the resident matrices.
+    pub fn witness_map(&mut self, full_assignment: &[Fr], domain_size: usize) -> Result<Vec<Fr>, GpuError> {
+        let w = pack::fr_vec_words(full_assignment);
+        let mut h = vec![0u64; 4 * domain_size];
+        check(self.ctx, unsafe { ffi::g16_witness_map(self.ctx, w.as_ptr(), full_assignment.len(), h.as_mut_ptr()) })?;
+        Ok(h.chunks_exact(4)
+            .map(|c| Fr::new_unchecked(ark_ff::BigInt([c[0], c[1], c[2], c[3]])))
+            .collect())
+    }
+}
+
+impl Drop for GpuProver {
+    fn drop(&mut self) {
+        unsafe { ffi::g16_ctx_destroy(self.ctx) }
+    }
+}

@@ -54,9 +54,22 @@ def main(ref):
     # sanity: counts match the fixture's sizes (n_vars 4, n_public 1, domain 4)
     assert [len(sections[k]) for k in ("ic", "a_query", "b_g1_query", "b_g2_query", "l_query", "h_query")] == \
         [2, 4, 4, 4, 2, 4], {k: len(v) for k, v in sections.items()}
-    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
+    here = os.path.dirname(os.path.abspath(__file__))
+    dst = os.path.join(here, "reference_vectors.json")
     json.dump(out, open(dst, "w"), indent=0)
     print("wrote", dst)
+    # binary FIXTURES (data, not code) the reference's tests and bench read from test-vectors/;
+    # complex-circuit-10000-10000.r1cs is the default workload of benches/groth16.rs:87-108 (its
+    # .zkey is not in the snapshot: the tests mint a trapdoor key for it)
+    import shutil
+    for rel in ("test-vectors/test.zkey", "test-vectors/mycircuit.r1cs", "test-vectors/circuit2.r1cs",
+                "test-vectors/complex-circuit/complex-circuit-10000-10000.r1cs",
+                "test-vectors/complex-circuit/input.json"):
+        src = os.path.join(ref, rel)
+        name = os.path.basename(rel) if "input.json" not in rel else "complex-circuit-input.json"
+        if os.path.exists(src):
+            shutil.copyfile(src, os.path.join(here, name))
+            print("copied", rel)
 
 
 if __name__ == "__main__":

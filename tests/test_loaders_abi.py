@@ -4,6 +4,7 @@ product path fails loudly without a GPU (no fallback)."""
 import ctypes as C
 import json
 import os
+import sys
 import re
 
 import numpy as np
@@ -136,7 +137,10 @@ def test_r1cs_loader_golden_and_errors(gpulib, vec, golden):
         with pytest.raises(cc.SerializationError, match=msg):
             cc.R1CSFile(bytes(d), lib=gpulib)
     # fixtures: same values as the oracle parser
-    for name in ("mycircuit.r1cs", "circuit2.r1cs"):
+    # complex-circuit-10000-10000.r1cs: the reference bench's default circuit (benches/groth16.rs:
+    # 87-108); its HEADER section comes first in the file, the other fixtures have the constraints
+    # first (r1cs_reader.rs:80-87 accepts any order)
+    for name in ("mycircuit.r1cs", "circuit2.r1cs", "complex-circuit-10000-10000.r1cs"):
         data = open(os.path.join(golden, name), "rb").read()
         f = cc.R1CSFile(data, lib=gpulib)
         ref = o.read_r1cs(data)
@@ -145,6 +149,24 @@ def test_r1cs_loader_golden_and_errors(gpulib, vec, golden):
             want = [(wdx, cf) for con in ref["constraints"] for wdx, cf in con[k]]
             assert flat == want, (name, k)
         assert [int(x) for x in f.wire_mapping] == ref["wire_mapping"]
+
+
+def test_reference_bench_circuit_witness_by_forward_solve(gpulib, golden):
+    """complex-circuit-10000-10000.r1cs + input a = 3 (test-vectors/complex-circuit/input.json): the
+    witness bench.py derives without the WASM calculator satisfies every row of the reference's
+    own constraint file (checked with plain integers), and has the template's shape
+    (b[0] = a^2, b[i] = b[i-1]^2, 10000 rows, 2 instance variables)."""
+    import circom_compat_amd as cc
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert json.load(open(os.path.join(golden, "complex-circuit-input.json"))) == {"a": "3"}
+    mats, (a, b, c), w, n_vars = bench.complex_circuit(cc)
+    assert (mats.num_constraints, mats.num_instance_variables, n_vars) == (10000, 2, 10002)
+    ref = o.read_r1cs(open(os.path.join(golden, "complex-circuit-10000-10000.r1cs"), "rb").read())
+    lc = lambda terms: sum(cf * w[j] for j, cf in terms) % o.R_MOD
+    assert all(lc(A) * lc(B) % o.R_MOD == lc(Cc) for A, B, Cc in ref["constraints"])
+    assert w[0] == 1 and w[2] == 3 and w[3] == 9 and w[4] == 81
+    assert w[1] == pow(3, 1 << 10000, o.R_MOD)              # c = a^(2^NUM_VARIABLES)
 
 
 def test_wtns_and_public_inputs(gpulib, golden):
