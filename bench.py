@@ -74,33 +74,37 @@ def chain_circuit(cc, k):
     return mats, (A, B, Cm), w, n_vars
 
 
-def dense_skewed_circuit(cc, k, seed=5, n_bits=4096):
+def dense_skewed_circuit(cc, k, seed=5, n_bits=4096, n_wide=64, p_bit=0.64):
     """SURVEY 8(d) config-5 substitute (the shape of circuit2.r1cs: ~3 / ~2 nnz per row): m = 2^k - 2
-    rows, row i defines a fresh wire out_i = (A_i.w)(B_i.w).  ~60 % of the rows are bit logic
-    ((b_i + b_j - b_k) * b or (..) * (1 - b): results in {0, 1, 2, -1}), the rest mix arbitrary
-    earlier wires with small +- coefficients, so that >= 50 % of the witness is in {0, 1} and the
-    rest is spread from tiny to uniform 254-bit values -- hot MSM buckets, as circom witnesses have."""
+    rows, row i defines a fresh wire out_i = (A_i.w)(B_i.w).  p_bit of the rows are bit logic
+    ((b_i + b_j - b_k) * b or (..) * (1 - b): results in {0, 1, 2, -1}), the rest mix earlier
+    full-width wires with small +- coefficients, so that roughly 60 % of the witness is in {0, 1}, a
+    few % are 2 / r - 1, and the rest is uniform 254-bit -- hot MSM buckets, as circom witnesses
+    (bit decompositions next to hash state) have."""
     rng = random.Random(seed)
     m = (1 << k) - 2
-    w = [1, 0] + [rng.randrange(2) for _ in range(n_bits)]
+    w = [1, 0] + [rng.randrange(2) for _ in range(n_bits)] + [rng.randrange(R_MOD) for _ in range(n_wide)]
     bits = list(range(2, 2 + n_bits))
+    wide = list(range(2 + n_bits, 2 + n_bits + n_wide))
     coeffs = [1, R_MOD - 1, 2, R_MOD - 2, 3]
     a_rp, b_rp, c_rp = [0], [0], [0]
     a_col, a_val, b_col, b_val, c_col = [], [], [], [], []
     for i in range(m - 1):
         hi = len(w)
-        if rng.random() < 0.6:
+        if rng.random() < p_bit:
             ta = [(rng.choice(bits), 1), (rng.choice(bits), 1), (rng.choice(bits), R_MOD - 1)]
             tb = [(rng.choice(bits), 1)] if rng.random() < 0.5 else [(0, 1), (rng.choice(bits), R_MOD - 1)]
         else:
-            ta = [(rng.randrange(2, hi), rng.choice(coeffs)) for _ in range(3)]
-            tb = [(rng.randrange(2, hi), rng.choice(coeffs)) for _ in range(2)]
+            ta = [(rng.choice(wide), rng.choice(coeffs)) for _ in range(3)]
+            tb = [(rng.choice(wide), rng.choice(coeffs)) for _ in range(2)]
         va = sum(c * w[j] for j, c in ta) % R_MOD
         vb = sum(c * w[j] for j, c in tb) % R_MOD
         val = va * vb % R_MOD
         w.append(val)
         if val in (0, 1):
             bits.append(hi)
+        elif val.bit_length() > 200:
+            wide.append(hi)
         for j, c in ta:
             a_col.append(j)
             a_val.append(c)
@@ -294,7 +298,7 @@ def main():
 
     # ---- per-rank path: RCCL collectives on a torch stream the library orders itself against
     if mode == "ranks":
-        xs = torch.cuda.Stream()
+        xs = torch.cuda.Stream(priority=-1)   # high priority: shares a hardware queue with the aux stream, not with the MSM streams
         prover.set_exchange_stream(xs.cuda_stream)
         dist_wm = prover.dist_wm
         if dist_wm:

@@ -335,7 +335,20 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
   c->rank = o.rank;
   c->world = o.world;
   g16_status st = guarded(c, [&]() -> g16_status {
-    G16_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // G16_MSM_CU_RESERVE=n (measurement knob, sharded ranks): the main (MSM) stream may not use the
+    // first n CUs, so the witness-map chain on the aux stream never waits for a round of the
+    // persistent accumulation grid to retire
+    int cu_reserve = 0;
+    if (const char* e = getenv("G16_MSM_CU_RESERVE")) cu_reserve = atoi(e);
+#ifndef G16_EMU
+    if (cu_reserve > 0 && cu_reserve < 128) {
+      uint32_t mask[8];
+      for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
+      for (int i = 0; i < cu_reserve; ++i) mask[i >> 5] &= ~(1u << (i & 31));
+      G16_HIP(hipExtStreamCreateWithCUMask(&c->stream, 8, mask));
+    } else
+#endif
+      G16_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     G16_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     G16_HIP(hipStreamCreateWithFlags(&c->red, hipStreamNonBlocking));
     {

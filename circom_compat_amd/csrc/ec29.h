@@ -99,14 +99,10 @@ struct XYZZ29 {
         return;
       }
     }
-    // Pp in (-6p, 9p) per component.  G2 squares it by the complex method (F29x2::sqr_wide): the
-    // factors (c0 +- c1) reach 18p x 15p = 270 p^2, so PP.c0 lies in (-1.6p, 2.6p) instead of the
-    // M class; every later use has room for that (41 p^2, 32 p^2, 10 p^2 below).  R is within
-    // (-4p, 5p), so R.sqr_wide() stays in the M class.
-    LF PP = Pp.sqr_wide();                         // G1: M; G2: c0 in (-1.6p, 2.6p)
-    LF PPP = Pp * PP;                              // M   (9p x 2.6p + 9p x 2p = 41 p^2)
-    LF Q = x * PP;                                 // M   (7p x 2.6p + 7p x 2p = 32 p^2)
-    LF X3 = (R.sqr_wide() - PPP - Q.dbl()).carry();  // S: (-7p, 5p)
+    LF PP = Pp.sqr();                              // M
+    LF PPP = Pp * PP;                              // M
+    LF Q = x * PP;                                 // M
+    LF X3 = (R.sqr() - PPP - Q.dbl()).carry();     // S: (-7p, 5p)
     LF Y3 = LF::mul_sub(R, Q - X3, y, PPP);        // M (S for Fq2)
     zz = zz * PP;
     zzz = zzz * PPP;
@@ -126,10 +122,10 @@ struct XYZZ29 {
     LF Pp = U2 - acc.x;
     LF R = S2 - acc.y;
     *special = !acc_inf && !p.inf && Pp.maybe_zero_mod_p();
-    LF PP = Pp.sqr_wide();
+    LF PP = Pp.sqr();
     LF PPP = Pp * PP;
     LF Q = acc.x * PP;
-    LF X3 = (R.sqr_wide() - PPP - Q.dbl()).carry();
+    LF X3 = (R.sqr() - PPP - Q.dbl()).carry();
     LF Y3 = LF::mul_sub(R, Q - X3, acc.y, PPP);
     XYZZ29 r{X3, Y3, acc.zz * PP, acc.zzz * PPP};
     if (acc_inf) r = XYZZ29{p.x, p.y, LF::one(), LF::one()};

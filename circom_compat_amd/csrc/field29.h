@@ -41,14 +41,13 @@ constexpr uint32_t MASK = (1u << 29) - 1u;
 // Identity the optimiser cannot see through (device code only).  Limbs that come out of a mask
 // are KNOWN non-negative, and LLVM then lowers limb * signed-limb as zext x sext: two
 // v_mad_u64_u32 plus a sign fix-up (v_ashrrev_i32 + 2 v_mov) instead of ONE v_mad_i64_i32.
-// Hiding the known bits makes every limb product a single signed multiply-add.
-#ifndef F29_OPAQUE_LEVEL
-#define F29_OPAQUE_LEVEL 2  // 0: off, 1: limbs unpacked from HBM words, 2: product outputs as well
-#endif
-template <int LEVEL = 1>
+// Hiding the known bits makes every limb product a single signed multiply-add.  Same-box A/B at
+// 2^22 (profiles/r02_ab_field_variants.txt): the G2 accumulation gains 2.3 % with the points'
+// limbs hidden (12.40 -> 12.13 ms), the G1 accumulation loses ~1.5 %, hiding product outputs as
+// well gains nothing -- so only Lazy<Fq2>::load_packed uses it.
 G16_HD int32_t opaque(int32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (F29_OPAQUE_LEVEL >= LEVEL) asm("" : "+v"(x));
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(F29_NO_OPAQUE)
+  asm("" : "+v"(x));
 #endif
   return x;
 }
@@ -205,13 +204,10 @@ struct F29 {
 
   // ---- Montgomery product a b / 2^261 ----------------------------------------------------------
   friend G16_HD F29 operator*(const F29& a, const F29& b) {
+    constexpr int N = f29::N;
 #ifdef F29_CHECK
     check_mul_inputs(a, b);
 #endif
-    return mul_unchecked(a, b);
-  }
-  static G16_HD F29 mul_unchecked(const F29& a, const F29& b) {
-    constexpr int N = f29::N;
     int64_t acc = 0;
     int32_t m[N];
     F29 r;
@@ -231,7 +227,7 @@ struct F29 {
       for (int i = k - N + 1; i < N; ++i) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
 #pragma unroll
       for (int i = k - N + 1; i < N; ++i) acc += (int64_t)m[i] * (int64_t)C::MOD.v[k - i];
-      r.l[k - N] = f29::opaque<2>((int32_t)((uint32_t)acc & f29::MASK));
+      r.l[k - N] = (int32_t)((uint32_t)acc & f29::MASK);
       acc >>= 29;
     }
     r.l[N - 1] = (int32_t)acc;
@@ -269,7 +265,7 @@ struct F29 {
       }
 #pragma unroll
       for (int i = k - N + 1; i < N; ++i) acc += (int64_t)m[i] * (int64_t)C::MOD.v[k - i];
-      r.l[k - N] = f29::opaque<2>((int32_t)((uint32_t)acc & f29::MASK));
+      r.l[k - N] = (int32_t)((uint32_t)acc & f29::MASK);
       acc >>= 29;
     }
     r.l[N - 1] = (int32_t)acc;
@@ -309,26 +305,12 @@ struct F29 {
       } else {
 #pragma unroll
         for (int i = k - N + 1; i < N; ++i) acc += (int64_t)m[i] * (int64_t)C::MOD.v[k - i];
-        r.l[k - N] = f29::opaque<2>((int32_t)((uint32_t)acc & f29::MASK));
+        r.l[k - N] = (int32_t)((uint32_t)acc & f29::MASK);
       }
       acc >>= 29;
     }
     r.l[N - 1] = (int32_t)acc;
     return r;
-  }
-
-  // the squaring of the mixed addition (see F29x2::sqr_wide): nothing to gain in the base field
-  G16_HD F29 sqr_wide() const { return sqr(); }
-  // product with a RELAXED value contract (|a b| < 300 p^2 instead of 169 p^2): same arithmetic,
-  // the result lies in (-1.8 p, 2.8 p) instead of (-p, 2p); limbs normalised as for operator*
-  static G16_HD F29 mul_wide(const F29& a, const F29& b) {
-#ifdef F29_CHECK
-    check_mul_inputs(a, b, 300.0L);
-    F29 x = a, y = b;
-    return mul_unchecked(x, y);
-#else
-    return a * b;
-#endif
   }
 
   // ---- exact (slow) canonicalisation: the unique representative in [0, p), limbs normalised ----
@@ -394,8 +376,13 @@ struct F29 {
     r.l[6] = (int32_t)(((w[5] >> 14) | (w[6] << 18)) & f29::MASK);
     r.l[7] = (int32_t)(((w[6] >> 11) | (w[7] << 21)) & f29::MASK);
     r.l[8] = (int32_t)(w[7] >> 8);
+    return r;
+  }
+  // the same with the limbs' known-zero top bits hidden from the optimiser (see f29::opaque)
+  static G16_HD F29 unpack_opaque(const uint32_t (&w)[8]) {
+    F29 r = unpack(w);
 #pragma unroll
-    for (int i = 0; i < f29::N; ++i) r.l[i] = f29::opaque<1>(r.l[i]);
+    for (int i = 0; i < f29::N; ++i) r.l[i] = f29::opaque(r.l[i]);
     return r;
   }
   // limbs of a canonical value (all in [0, 2^29), top < 2^24) -> 8 words
@@ -455,10 +442,10 @@ struct F29 {
     long double v = fabsl(approx_over_p(a) * approx_over_p(b)) + fabsl(approx_over_p(c) * approx_over_p(d));
     assert(v < 168.9L && "F29 mul2: value bound exceeded");
   }
-  static void check_mul_inputs(const F29& a, const F29& b, long double bound = 168.9L) {
+  static void check_mul_inputs(const F29& a, const F29& b) {
     {
       long double v = fabsl(approx_over_p(a) * approx_over_p(b));
-      assert(v < bound && "F29 mul: value bound exceeded");
+      assert(v < 168.9L && "F29 mul: value bound exceeded");
     }
     for (int k = 0; k < 2 * f29::N - 1; ++k) {
       __int128 s = 0;
@@ -601,19 +588,6 @@ struct F29x2 {
     return F29x2{B::mul_sub(a.c0, b.c0, a.c1, b.c1), B::mul2(a.c0, b.c1, a.c1, b.c0)};
   }
   G16_HD F29x2 sqr() const { return F29x2{B::mul_sub(c0, c0, c1, c1), c0.dbl() * c1}; }
-  // "complex" squaring (c0 + c1)(c0 - c1) | 2 c0 c1: TWO single products (2 x 171 multiply-adds)
-  // instead of a merged pair + one (252 + 171).  Price: the first product sees the SUM of the
-  // component bounds on both sides -- up to 18p x 15p = 270 p^2 for the mixed addition's
-  // Pp = U2 - X -- so c0 of the result lies in (-1.6p, 2.6p) rather than in (-p, 2p).  Only for
-  // callers whose next use of the result tolerates that: the two squarings of XYZZ29::madd /
-  // madd_select (ec29.h lists the bounds).  Inputs: limbs within +-(2^29 + 2^4), |c_i| < 9 p.
-#ifndef F29_NO_COMPLEX_SQR
-  G16_HD F29x2 sqr_wide() const {
-    return F29x2{B::mul_wide((c0 + c1).carry(), (c0 - c1).carry()), c0.dbl() * c1};
-  }
-#else
-  G16_HD F29x2 sqr_wide() const { return sqr(); }
-#endif
   // a b - c d; components carried (two separate reductions per component would overflow the
   // 64-bit columns if merged: 36 products)
   static G16_HD F29x2 mul_sub(const F29x2& a, const F29x2& b, const F29x2& c, const F29x2& d) {
@@ -657,7 +631,7 @@ template <> struct Lazy<Fq> {
 template <> struct Lazy<Fq2> {
   using type = F29x2<FqParams>;
   static G16_HD type load_packed(const Fq2& raw) {
-    return type{F29<FqParams>::unpack(raw.c0.v), F29<FqParams>::unpack(raw.c1.v)};
+    return type{F29<FqParams>::unpack_opaque(raw.c0.v), F29<FqParams>::unpack_opaque(raw.c1.v)};
   }
   static G16_HD Fq2 store_packed(const type& a) {
     Fq2 r;

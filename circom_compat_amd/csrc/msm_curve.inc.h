@@ -57,11 +57,16 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offse
 template <class F>
 struct AccWay {
   using LF = typename Lazy<F>::type;
-  uint32_t seg, pos, end, g, bend, en_next, en_next2;
+  uint32_t seg, pos, end, g, bend, bnext, en_next, en_next2;  // bend = offset[g+1], bnext = offset[g+2]
   bool live;
   XYZZ29<LF> acc;
   Affine<F> raw_next;
 };
+
+// G16_DEBUG_GATHER_MASK (measurement only, wrong results): point index &= mask, i.e. every gather
+// falls into a cache-resident set of points -- separates the cost of the random HBM gathers from
+// the arithmetic of the accumulation kernel
+__device__ uint32_t g_gather_mask = 0xffffffffu;
 
 template <class F>
 __device__ __forceinline__ void acc_fetch(const Affine<F>* __restrict__ pts, uint32_t npts,
@@ -69,7 +74,11 @@ __device__ __forceinline__ void acc_fetch(const Affine<F>* __restrict__ pts, uin
   const uint32_t idx = en & MSM_IDX_MASK;
   if (idx >= idx_min) {
     const uint32_t plane = (en >> MSM_IDX_BITS) & 31u;
+#ifdef G16_DEBUG_GATHER
+    raw = pts[(size_t)(plane & g_gather_mask) * npts + ((idx - idx_min) & g_gather_mask)];
+#else
     raw = pts[(size_t)plane * npts + (idx - idx_min)];
+#endif
   } else {
     raw = Affine<F>::infinity();  // entry below this query's range (public inputs of L)
   }
@@ -87,37 +96,49 @@ __device__ __forceinline__ void acc_way_init(AccWay<F>& w, uint32_t seg, uint32_
   w.acc = XYZZ29<typename Lazy<F>::type>::infinity();
   w.raw_next = Affine<F>::infinity();
   w.g = 0;
-  w.bend = 0;
+  w.bend = w.bnext = 0;
   w.en_next = w.en_next2 = 0;
   if (w.live) {
     w.g = bucket_of(offset, nb, w.pos);
     w.bend = offset[w.g + 1];
+    w.bnext = offset[w.g + 2 < nb ? w.g + 2 : nb];
     w.en_next = entries[w.pos];
     w.en_next2 = w.pos + 1 < w.end ? entries[w.pos + 1] : 0u;
     acc_fetch<F>(pts, npts, idx_min, w.en_next, w.raw_next);
   }
 }
 
-// bucket-boundary bookkeeping + consume the prefetched point + issue the next fetches
+// consume the prefetched point + bucket-boundary bookkeeping + issue the next fetches.
+// Order matters for the memory counter (vmcnt is in order and counts stores too): the point
+// prefetched one iteration ago is unpacked FIRST, so that the wait for it sits in front of the
+// boundary block; that block's partial store and its look-ahead load of the next bucket end are then
+// only waited for one iteration later (at the next point's unpack), when they have long completed.
+// With the boundary block first, every wave drained its fresh stores + a dependent offset[] load
+// whenever one of its lanes crossed a bucket boundary (~half of the iterations).
 template <class F>
 __device__ __forceinline__ Aff29<typename Lazy<F>::type> acc_way_prepare(
     AccWay<F>& w, bool* step, const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min,
-    const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset,
+    const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset, uint32_t nb,
     MsmAcc<F>* __restrict__ partial) {
   using LF = typename Lazy<F>::type;
   *step = w.live && w.pos < w.end;
-  if (*step && w.pos == w.bend) {  // crossed into the next non-empty bucket: emit, restart
-    partial[w.g + w.seg] = w.acc;
-    w.acc = XYZZ29<LF>::infinity();
-    do {
-      ++w.g;
-      w.bend = offset[w.g + 1];
-    } while (w.bend == w.pos);
-  }
   const uint32_t en = w.en_next;
   Aff29<LF> p = load_packed_affine<F>(w.raw_next);
   if (en >> 31) p.y = p.y.neg().carry();
   if (!*step) p.inf = true;
+  if (*step && w.pos == w.bend) {  // crossed into the next non-empty bucket: emit, restart
+    partial[w.g + w.seg] = w.acc;
+    w.acc = XYZZ29<LF>::infinity();
+    ++w.g;
+    w.bend = w.bnext;  // fetched during the previous iteration
+    while (w.bend == w.pos) {  // runs of empty buckets (rare): chase the array
+      ++w.g;
+      w.bend = offset[w.g + 1];
+    }
+  }
+  // look-ahead for the next crossing, EVERY iteration (a conditional load would need a copy into
+  // the loop-carried register at the end of the boundary block, i.e. a wait for it right there)
+  if (*step) w.bnext = offset[w.g + 2 < nb ? w.g + 2 : nb];
   w.en_next = w.en_next2;
   if (*step && w.pos + 2 < w.end) w.en_next2 = entries[w.pos + 2];
   if (*step && w.pos + 1 < w.end) acc_fetch<F>(pts, npts, idx_min, w.en_next, w.raw_next);
@@ -155,7 +176,7 @@ __global__ void __launch_bounds__(ACC_THREADS)
     if (!w.live) break;  // segments are handed out in order: nothing left for later threads either
     for (uint32_t it = 0; it < S; ++it) {
       bool step, special;
-      const Aff29<LF> p = acc_way_prepare<F>(w, &step, pts, npts, idx_min, entries, offset, partial);
+      const Aff29<LF> p = acc_way_prepare<F>(w, &step, pts, npts, idx_min, entries, offset, nb, partial);
       const XYZZ29<LF> r = XYZZ29<LF>::madd_select(w.acc, p, &special);
       acc_way_commit<F>(w, step, r, special, p);
     }
@@ -383,6 +404,16 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
   if (slot < 0 || slot >= work.batch) throw std::runtime_error("msm_accumulate: bad workspace slot");
   // persistent grid: cfg.lanes lanes, each owning an equal segment of the sorted entry list
   const uint32_t grid = cfg.lanes / ACC_THREADS;
+#ifdef G16_DEBUG_GATHER
+  static const bool mask_set = [] {
+    if (const char* e = getenv("G16_DEBUG_GATHER_MASK")) {
+      const uint32_t m = (uint32_t)strtoul(e, nullptr, 0);
+      G16_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gather_mask), &m, sizeof m));
+    }
+    return true;
+  }();
+  (void)mask_set;
+#endif
   int id = tm ? tm->begin(acc_stage, stream) : -1;
   G16_LAUNCH((k_bucket_accumulate<F>), grid, ACC_THREADS, 0, stream, (const Affine<F>*)P.pts.p,
              P.count, idx_min, (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb,

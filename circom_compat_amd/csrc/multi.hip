@@ -278,8 +278,16 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
     M->ch[g] = c;
     Multi::Dev& d = *M->dv[g];
     G16_HIP(hipSetDevice(c->device));
+    // Copy streams are created with the witness-map (aux) stream's HIGH priority on purpose: HIP
+    // maps streams onto a few hardware queues per priority level (4 by default, GPU_MAX_HW_QUEUES)
+    // and streams that share a queue serialise.  A copy stream that lands on the queue of the main /
+    // side / red stream would sit behind the whole MSM chain (measured: the exchange then starts
+    // after the last accumulation, profiles/r02_rank8_timeline_before.txt); sharing a queue with aux
+    // or with another copy stream costs nothing, they are one dependency chain anyway.
+    int prio_lo = 0, prio_hi = 0;
+    G16_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     d.cs.assign(n_dev, nullptr);
-    for (auto& s2 : d.cs) G16_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    for (auto& s2 : d.cs) G16_HIP(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio_hi));
     for (int x = 0; x < 2; ++x) {
       d.arrived[x].assign(n_dev, nullptr);
       for (auto& e : d.arrived[x]) G16_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -338,7 +338,7 @@ def test_per_rank_api_with_exchange_stream_no_host_syncs(gpulib):
     w = cc.fr_from_ints(w_ints)
     w_dev = torch.from_numpy(w.view(np.int64)).cuda()
     torch.cuda.synchronize()
-    xs = torch.cuda.Stream()
+    xs = torch.cuda.Stream(priority=-1)   # high priority: shares a hardware queue with the aux stream, not with the MSM streams
     provers = [cc.Prover(pk, mats, rank=g, world=world, dist_wm=True) for g in range(world)]
     for p in provers:
         p.set_exchange_stream(xs.cuda_stream)
