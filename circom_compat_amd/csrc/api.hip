@@ -440,7 +440,10 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
       // this rank's h scalars are the evaluations e = global_index(t): gather the matching points
       std::vector<G1Affine> mine(lh);
       const G1Affine* hq = (const G1Affine*)key->h_query;
-      for (uint32_t t = 0; t < lh; ++t) mine[t] = hq[c->wd.global_index(t)];
+      // byte copies: the caller's arrays carry no alignment (zero-copy views of zkey sections start
+      // at arbitrary file offsets) and G1Affine is an over-aligned type
+      for (uint32_t t = 0; t < lh; ++t)
+        memcpy((void*)&mine[t], (const uint8_t*)hq + (size_t)c->wd.global_index(t) * sizeof(G1Affine), sizeof(G1Affine));
       c->ptsH.init(mine.data(), lh, c->cfg_h, s);
       G16_HIP(hipStreamSynchronize(s));  // `mine` is read by the async upload
     } else {

@@ -517,3 +517,22 @@ def test_domain_too_large_and_bad_matrices(lib):
     assert "row_ptr" in str(e.value)
     with pytest.raises(cc.G16Error):
         cc.Prover(None, cc.ConstraintMatrices(2, 2, 1, ok, ok), lib=lib)     # n_vars is required
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0, 0, 0, 0]])
+def test_multi_device_prover_on_the_reference_zkey(lib, golden, devices):
+    """test.zkey (4 wires, domain 4) through read_zkey -- zero-copy, UNALIGNED views of the file's point
+    sections -- on 2 / 3 / 4 ranks: shards of one or zero points, the smallest four-step split
+    (n1 = n2 = 2), bytes == oracle (SURVEY C.1 inputs)."""
+    import circom_compat_amd as cc
+    data = open(os.path.join(golden, "test.zkey"), "rb").read()
+    pk, mats = cc.read_zkey(data, lib)
+    opk, omats = o.read_zkey(data)
+    w = [1, 33, 3, 11]
+    r = 3413513218498352040262653353725127729454431939539290118844322056224532443637
+    s = 6077776500692565155461894309070795882353485867345896979329447163197530625403
+    want = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, r, s, omats, 2, 1, w))
+    pr = cc.Prover(pk, mats, lib=lib, devices=devices)
+    assert pr.prove(r, s, w).raw == want
+    assert pr.prove(0, 0, w).raw == o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, 0, 0, omats, 2, 1, w))
+    pr.close()
