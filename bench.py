@@ -450,9 +450,12 @@ def main():
             pr_c.close()
             return pk_c, mats_c, wc, gpu_small.raw
 
-        kp = min(args.cpu_log2, k)
+        # N > 1: only a small byte comparison (torchrun pins OMP_NUM_THREADS=1: the timed baseline
+        # belongs to the N = 1 line)
+        kp = min(args.cpu_log2, k) if n_gpus == 1 else min(args.cpu_log2, k, 14)
         pk_c, mats_c, wc, gpu_small = small_case(kp)
-        cpu_ref.prove(pk_c, mats_c, rs[0:1].copy(), rs[1:2].copy(), wc)      # thread pool warm-up
+        if n_gpus == 1:
+            cpu_ref.prove(pk_c, mats_c, rs[0:1].copy(), rs[1:2].copy(), wc)  # thread pool warm-up
         out, t_probe = cpu_prove(pk_c, mats_c, wc, 1)
         parity["bit_identical_to_cpu_at_2^%d" % kp] = bool(out == gpu_small)
         est_full = t_probe * (2 ** (k - kp)) * 1.15

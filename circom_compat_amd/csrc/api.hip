@@ -220,6 +220,35 @@ namespace g16 {
 
 void rank_collect_times(g16_ctx* c) { collect_times(c); }
 
+// one whole single-device proof, enqueue only: (r, s) from and the proof to the ctx's pinned buffer
+static void enqueue_prove(g16_ctx* c, const Fr* w_dev) {
+  hipStream_t s = c->stream;
+  G16_HIP(hipMemcpyAsync(c->rs_dev.p, c->pin_io, 64, hipMemcpyHostToDevice, s));
+  // fork: the (r, s)-only part of the finalisation runs beside the witness map / MSMs
+  G16_HIP(hipEventRecord(c->ev_start, s));
+  G16_HIP(hipStreamWaitEvent(c->side, c->ev_start, 0));
+  fin_fixed(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, c->side);
+  G16_HIP(hipEventRecord(c->ev_fixed, c->side));
+  run_msms(
+      c, w_dev,
+      [&](hipStream_t from) {
+        // A and B1 are enqueued: g_a, g1_b and the two variable-base products overlap L / B2 / H
+        G16_HIP(hipEventRecord(c->ev_ab, from));
+        G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
+        fin_var(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->fin_scr.p, c->out_dev.p, c->side);
+      },
+      [&] {
+        // the B2 sum is there: B (assembly + Fq2 inversion) hides under the H MSM
+        G16_HIP(hipStreamWaitEvent(c->red, c->ev_fixed, 0));
+        fin_b(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, c->red);
+      });
+  G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));  // join
+  int id = c->timer.enabled ? c->timer.begin(ST_FINALIZE, s) : -1;
+  fin_final(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, s);
+  c->timer.end(id, s);
+  G16_HIP(hipMemcpyAsync(c->pin_io + 64, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
+}
+
 // this rank's r*A-side products: s*A and r*B1 (variable-base, one wave each) overlap its L / B2 / H MSMs
 static void fork_partial_var(g16_ctx* c, hipStream_t from) {
   G16_HIP(hipEventRecord(c->ev_ab, from));
@@ -419,6 +448,11 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     c->fin_tab.alloc(1);
     c->fin_scr.alloc(1);
     c->out_dev.alloc(G16_PROOF_BYTES + G16_PARTIAL_BYTES * (size_t)(c->world + 1));
+    {
+      void* pin = nullptr;
+      G16_HIP(hipHostMalloc(&pin, 64 + G16_PROOF_BYTES, 0));
+      c->pin_io = (uint8_t*)pin;
+    }
 
     // MSM configurations: the four witness queries share one sort, hence one (c, W, planes)
     const size_t reserve = (size_t)3 << 30;
@@ -527,6 +561,7 @@ void g16_ctx_destroy(g16_ctx* c) {
   if (c->ev_part) (void)hipEventDestroy(c->ev_part);
   if (c->ev_user) (void)hipEventDestroy(c->ev_user);
   if (c->pinned_w) (void)hipHostFree(c->pinned_w);
+  if (c->pin_io) (void)hipHostFree(c->pin_io);
   delete c;
 }
 
@@ -633,34 +668,11 @@ g16_status g16_prove_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], 
   if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
   return guarded(c, [&]() -> g16_status {
     hipStream_t s = c->stream;
-    uint64_t rs[8];
-    memcpy(rs, r, 32);
-    memcpy(rs + 4, s_, 32);
-    G16_HIP(hipMemcpyAsync(c->rs_dev.p, rs, 64, hipMemcpyHostToDevice, s));
-    // fork: the (r, s)-only part of the finalisation runs beside the witness map / MSMs
-    G16_HIP(hipEventRecord(c->ev_start, s));
-    G16_HIP(hipStreamWaitEvent(c->side, c->ev_start, 0));
-    fin_fixed(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, c->side);
-    G16_HIP(hipEventRecord(c->ev_fixed, c->side));
-    run_msms(
-        c, (const Fr*)w_dev,
-        [&](hipStream_t from) {
-          // A and B1 are enqueued: g_a, g1_b and the two variable-base products overlap L / B2 / H
-          G16_HIP(hipEventRecord(c->ev_ab, from));
-          G16_HIP(hipStreamWaitEvent(c->side, c->ev_ab, 0));
-          fin_var(c->key_dev.p, c->sums_dev.p, c->rs_dev.p, c->fin_scr.p, c->out_dev.p, c->side);
-        },
-        [&] {
-          // the B2 sum is there: B (assembly + Fq2 inversion) hides under the H MSM
-          G16_HIP(hipStreamWaitEvent(c->red, c->ev_fixed, 0));
-          fin_b(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, c->red);
-        });
-    G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));  // join
-    int id = c->timer.enabled ? c->timer.begin(ST_FINALIZE, s) : -1;
-    fin_final(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, s);
-    c->timer.end(id, s);
-    G16_HIP(hipMemcpyAsync(proof_out, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
+    memcpy(c->pin_io, r, 32);
+    memcpy(c->pin_io + 32, s_, 32);
+    enqueue_prove(c, (const Fr*)w_dev);
     G16_HIP(hipStreamSynchronize(s));
+    memcpy(proof_out, c->pin_io + 64, G16_PROOF_BYTES);
     collect_times(c);
     return G16_OK;
   });

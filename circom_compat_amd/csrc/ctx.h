@@ -62,6 +62,7 @@ struct g16_ctx {
   g16::DevBuf<g16::FinScratch> fin_scr;
   g16::DevBuf<uint8_t> out_dev;  // proof (256) | this rank's partial (1024) | gathered partials
   void* pinned_w = nullptr;      // g16_witness_host_buffer: page-locked staging for the witness
+  uint8_t* pin_io = nullptr;     // page-locked (r, s) [64 B] | proof [256 B] of g16_prove_dev
 
   g16::StageTimer timer;
   float st_ms[g16::ST_COUNT] = {0};
