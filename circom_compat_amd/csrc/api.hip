@@ -528,6 +528,7 @@ void g16_ctx_destroy(g16_ctx* c) {
   if (!c) return;
   if (c->multi) {  // parent of a multi-device prover: the children own all device state
     multi_destroy(c->multi);
+    if (c->pinned_w) (void)hipHostFree(c->pinned_w);
     delete c;
     return;
   }
