@@ -291,7 +291,14 @@ def main():
             dist_wm = os.environ.get("G16_BENCH_DIST_WM", "1") != "0"
             prover = cc.Prover(pk, mats, device=local_rank, rank=rank, world=world, dist_wm=dist_wm, **kw)
     dev = f"cuda:{torch.cuda.current_device()}" if active else "cpu"
-    w_dev = torch.from_numpy(w.view(np.int64)).to(dev) if active else None
+    w_dev = w_ptr = None
+    if active and mode == "inlib":
+        # resident on EVERY device before the timed region, as at N = 1 (g16_witness_upload): the ctx
+        # would otherwise peer-broadcast 32 N bytes from the first device inside every proof
+        w_ptr = prover.upload_witness(w)
+    elif active:
+        w_dev = torch.from_numpy(w.view(np.int64)).to(dev)
+        w_ptr = w_dev.data_ptr()
     if active:
         torch.cuda.synchronize()
     t_setup = time.time() - t_setup
@@ -330,9 +337,9 @@ def main():
 
     def step():
         if mode in ("single", "inlib"):
-            return prover.prove_dev(rs[0], rs[1], w_dev.data_ptr())
+            return prover.prove_dev(rs[0], rs[1], w_ptr)
         if dist_wm:
-            prover.dist_phase1(rs[0], rs[1], w_dev.data_ptr(), send.data_ptr())
+            prover.dist_phase1(rs[0], rs[1], w_ptr, send.data_ptr())
             exchange()
             prover.dist_phase2(recv.data_ptr(), send.data_ptr())
             exchange()
@@ -403,7 +410,7 @@ def main():
                 fn()
             return (time.perf_counter() - t1) / reps * 1e3
 
-        wptr = w_dev.data_ptr()
+        wptr = w_ptr
         parts = {"witness_map_ms": timed(lambda: prover.witness_map_dev(wptr, h_dev.data_ptr())),
                  "msm_A_ms": timed(lambda: prover.msm_g1_dev(0, wptr + 32, n_vars - 1)),
                  "msm_B1_ms": timed(lambda: prover.msm_g1_dev(1, wptr + 32, n_vars - 1)),

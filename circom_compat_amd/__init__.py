@@ -540,6 +540,13 @@ class Prover:
     def witness_buffer(self) -> int:
         return int(self.lib.g16_witness_buffer(self.ctx) or 0)
 
+    def upload_witness(self, full_assignment) -> int:
+        """witness resident in HBM (on every device of a multi-device ctx); returns the pointer to
+        pass to prove_dev()"""
+        w = _as_fr(full_assignment, self.lib)
+        self.lib.check(self.lib.g16_witness_upload(self.ctx, _np_ptr(w), w.shape[0]), self.ctx)
+        return self.witness_buffer()
+
     def witness_host_buffer(self) -> np.ndarray:
         """(n_vars, 4) uint64 view of the ctx's page-locked staging buffer (g16_witness_host_buffer)"""
         p = self.lib.g16_witness_host_buffer(self.ctx)

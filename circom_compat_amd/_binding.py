@@ -87,7 +87,7 @@ ABI_SYMBOLS = [
     "g16_msm_g2", "g16_prove", "g16_prove_dev", "g16_prove_partial", "g16_prove_partial_dev",
     "g16_prove_finish", "g16_dist_exchange_bytes", "g16_prove_dist_phase1", "g16_prove_dist_phase2",
     "g16_prove_dist_phase3", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info",
-    "g16_witness_buffer", "g16_witness_host_buffer", "g16_ctx_create_multi", "g16_dist_set_exchange_stream",
+    "g16_witness_buffer", "g16_witness_upload", "g16_witness_host_buffer", "g16_ctx_create_multi", "g16_dist_set_exchange_stream",
     "g16_partial_buffer", "g16_gather_buffer", "g16_prove_finish_dev", "g16_witness_map_dev", "g16_msm_g1_dev",
     "g16_msm_g2_dev", "g16_debug_ntt", "g16_debug_alu_bench", "g16_check_satisfied", "g16_zkey_write",
     "g16_setup_create", "g16_setup_create_ex", "g16_setup_destroy", "g16_setup_key",
@@ -144,6 +144,7 @@ class Library:
             "g16_ctx_info": (C.c_int, [vp, _u32p]),
             "g16_witness_buffer": (vp, [vp]),
             "g16_witness_host_buffer": (vp, [vp]),
+            "g16_witness_upload": (C.c_int, [vp, vp, C.c_size_t]),
             "g16_witness_map_dev": (C.c_int, [vp, vp, C.c_size_t, vp]),
             "g16_msm_g1_dev": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),
             "g16_msm_g2_dev": (C.c_int, [vp, vp, C.c_size_t, vp]),

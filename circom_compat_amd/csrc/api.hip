@@ -911,6 +911,17 @@ void* g16_witness_buffer(g16_ctx* c) {
   return c ? (void*)c->w_dev.p : nullptr;
 }
 
+g16_status g16_witness_upload(g16_ctx* c, const uint64_t* w, size_t n_vars) {
+  if (!c || !w) return fail(c, G16_ERR_INVALID, "null argument");
+  if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
+  if (c->multi) return multi_witness_upload(c, w);
+  return guarded(c, [&]() -> g16_status {
+    G16_HIP(hipMemcpyAsync(c->w_dev.p, w, (size_t)c->N * 32, hipMemcpyHostToDevice, c->stream));
+    G16_HIP(hipStreamSynchronize(c->stream));
+    return G16_OK;
+  });
+}
+
 void* g16_witness_host_buffer(g16_ctx* c) {
   if (!c) return nullptr;
   if (!c->pinned_w) {

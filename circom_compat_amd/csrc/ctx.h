@@ -99,6 +99,9 @@ void multi_destroy(Multi* m);
 // or a device pointer on children[0]'s device (true: peer-broadcast)
 g16_status multi_prove(g16_ctx* parent, const uint64_t r[4], const uint64_t s[4], const void* w,
                        bool w_on_device, uint8_t proof_out[G16_PROOF_BYTES]);
+// host witness -> every device's staging buffer; a later multi_prove(w = children[0]->w_dev.p, on
+// device) then moves nothing
+g16_status multi_witness_upload(g16_ctx* parent, const uint64_t* w);
 g16_ctx* multi_child(g16_ctx* parent, int index);  // nullptr when out of range / not a parent
 int multi_size(const g16_ctx* parent);
 

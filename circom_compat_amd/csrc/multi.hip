@@ -177,6 +177,7 @@ struct Multi {
     std::vector<hipEvent_t> arrived[2];     // [exchange][dst]: my chunk has landed in dst's recv buffer
   };
   std::vector<std::unique_ptr<Dev>> dv;  // DevBuf is not movable
+  bool witness_resident = false;  // g16_witness_upload: every child's w_dev holds the current witness
   StageRunner pool;
 };
 
@@ -216,6 +217,23 @@ void await_chunks(Multi& M, int g, int x, hipStream_t consumer) {
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace
+
+g16_status multi_witness_upload(g16_ctx* parent, const uint64_t* w) {
+  Multi& M = *parent->multi;
+  const size_t wbytes = (size_t)parent->N * 32;
+  M.witness_resident = false;
+  std::vector<std::function<void(int)>> st;
+  st.push_back([&](int g) {
+    g16_ctx* c = M.ch[g];
+    G16_HIP(hipSetDevice(c->device));
+    G16_HIP(hipMemcpyAsync(c->w_dev.p, w, wbytes, hipMemcpyHostToDevice, c->stream));
+    G16_HIP(hipStreamSynchronize(c->stream));
+  });
+  const int code = M.pool.run(st);
+  if (code != G16_OK) parent->err = M.pool.first_error;
+  else M.witness_resident = true;
+  return code;
+}
 
 g16_ctx* multi_child(g16_ctx* parent, int index) {
   if (!parent || !parent->multi || index < 0 || index >= parent->multi->G) return nullptr;
@@ -335,10 +353,15 @@ g16_status multi_prove(g16_ctx* parent, const uint64_t r[4], const uint64_t s_[4
   const size_t wbytes = (size_t)parent->N * 32;
   std::vector<const Fr*> wp(M.G, nullptr);
 
+  // witness already in every device's staging buffer (g16_witness_upload): nothing to move
+  const bool resident = w_on_device && M.witness_resident && w == (const void*)M.ch[0]->w_dev.p;
+  if (!resident) M.witness_resident = false;  // the staging buffers are about to be overwritten
   auto stage_witness = [&](int g) {
     g16_ctx* c = M.ch[g];
     G16_HIP(hipSetDevice(c->device));
-    if (!w_on_device) {
+    if (resident) {
+      wp[g] = c->w_dev.p;
+    } else if (!w_on_device) {
       // every device pulls its own copy over its own PCIe link
       G16_HIP(hipMemcpyAsync(c->w_dev.p, w, wbytes, hipMemcpyHostToDevice, c->stream));
       wp[g] = c->w_dev.p;

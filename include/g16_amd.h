@@ -201,6 +201,12 @@ const char* g16_stage_name(int stage);
 g16_status g16_ctx_info(const g16_ctx* ctx, uint32_t out[16]);
 /* device pointer of the ctx's witness staging buffer (n_vars x 32 bytes) for g16_prove_dev        */
 void* g16_witness_buffer(g16_ctx* ctx);
+/* Makes the witness resident: copies it into the ctx's device staging buffer -- into EVERY device's
+ * for a multi-device ctx -- and returns when it is there.  g16_prove_dev(ctx, r, s,
+ * g16_witness_buffer(ctx), ...) then proves from the resident copies without moving the witness
+ * (the multi-device ctx otherwise peer-broadcasts a device-resident witness from the first device
+ * inside every call).                                                                             */
+g16_status g16_witness_upload(g16_ctx* ctx, const uint64_t* w, size_t n_vars);
 /* page-locked HOST staging buffer (n_vars x 32 bytes, owned by the ctx): a caller that writes the
  * full assignment here (instead of into a Vec) gets the H2D copy of g16_prove at PCIe line rate   */
 void* g16_witness_host_buffer(g16_ctx* ctx);

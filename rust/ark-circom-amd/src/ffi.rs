@@ -158,6 +158,7 @@ extern "C" {
     pub fn g16_stage_name(stage: c_int) -> *const c_char;
     pub fn g16_ctx_info(ctx: *const g16_ctx, out: *mut u32) -> g16_status;
     pub fn g16_witness_buffer(ctx: *mut g16_ctx) -> *mut c_void;
+    pub fn g16_witness_upload(ctx: *mut g16_ctx, w: *const u64, n_vars: usize) -> g16_status;
     pub fn g16_witness_host_buffer(ctx: *mut g16_ctx) -> *mut c_void;
     pub fn g16_check_satisfied(device: c_int, a: *const g16_csr, b: *const g16_csr, c: *const g16_csr, num_constraints: u32, w: *const u64, n_vars: usize, first_unsatisfied: *mut i64) -> g16_status;
     pub fn g16_debug_ntt(device: c_int, data: *mut u64, log_n: c_int, inverse: c_int, algo: c_int) -> g16_status;

@@ -448,6 +448,13 @@ def test_in_library_multi_device_prover(lib, logm, devices):
         torch.cuda.synchronize()
         ptr = keep.data_ptr()
     assert pr.prove_dev(r, s, ptr).raw == o.proof_to_bytes(want)
+    # witness made resident on every device once (g16_witness_upload), then proofs that move nothing
+    res = pr.upload_witness(w)
+    assert res == pr.witness_buffer()
+    assert pr.prove_dev(r, s, res).raw == o.proof_to_bytes(want)
+    assert pr.prove_dev(r, s, res).raw == o.proof_to_bytes(want)
+    assert pr.prove(r, s, w).raw == o.proof_to_bytes(want)          # host path again (resets residency)
+    assert pr.prove_dev(r, s, ptr).raw == o.proof_to_bytes(want)    # broadcast path again
     # the sharded ctx proves only
     with pytest.raises(cc.G16Error):
         pr.witness_map(w)
