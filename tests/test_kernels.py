@@ -546,3 +546,30 @@ def test_multi_device_prover_on_the_reference_zkey(lib, golden, devices):
     assert pr.prove(r, s, w).raw == want
     assert pr.prove(0, 0, w).raw == o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, 0, 0, omats, 2, 1, w))
     pr.close()
+
+
+@pytest.mark.parametrize("n_pub,m", [(0, 5), (0, 1), (2, 1)])
+def test_no_public_inputs_and_single_constraint(lib, n_pub, m):
+    """edge shapes of the key: n_public = 0 (IC has one point, every wire but the constant has an L
+    point) and a single constraint (domain 2 / 4), on one device and on two ranks: bytes == oracle"""
+    import circom_compat_amd as cc
+    P = o.R_MOD
+    base = 1 + n_pub
+    n_vars = base + m + 1
+    cons = [([(base + i, 1)], [(base + i, 1)], [(base + i + 1, 1)]) for i in range(m)]
+    w = [1] + [7] * n_pub + [3]
+    for _ in range(m):
+        w.append(w[-1] * w[-1] % P)
+    rng = random.Random(1)
+    tox = [rng.randrange(1, P) for _ in range(5)]
+    opk = o.trapdoor_setup(cons, n_vars, n_pub, *tox)
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, n_pub + 1, n_vars, lib)
+    pk = H.pk_from_oracle(opk)
+    r, s = rng.randrange(P), rng.randrange(P)
+    want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), n_pub + 1, m, w)
+    assert o.verify_proof(opk, w[1:1 + n_pub], want)
+    for devices in (None, [0, 0]):
+        pr = cc.Prover(pk, mats, lib=lib, devices=devices)
+        assert pr.prove(r, s, w).raw == o.proof_to_bytes(want)
+        pr.close()
