@@ -36,7 +36,7 @@ from ._binding import G16Error, SerializationError, SynthesisError  # noqa: F401
 __all__ = ["read_zkey", "R1CSFile", "R1CS", "CircomCircuit", "CircomBuilder", "CircomReduction", "LibsnarkReduction", "Groth16",
            "Prover", "ProvingKey", "VerifyingKey", "ConstraintMatrices", "Proof", "G16Error",
            "SynthesisError", "SerializationError", "fr_from_ints", "fr_to_ints", "read_wtns",
-           "trapdoor_setup", "Csr", "write_zkey", "device_tensor"]
+           "trapdoor_setup", "Csr", "write_zkey", "device_tensor", "verify_batch"]
 
 FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
@@ -656,6 +656,39 @@ def trapdoor_setup(a: Csr, b: Csr, c: Csr, n_vars: int, n_public: int, toxic: Se
                       view(kd.h_query, kd.domain_size, 64), keepalive=handle)
 
 
+def verify_batch(vk: "VerifyingKey", proofs, public_inputs, device=0, lib: Optional[B.Library] = None):
+    """Groth16::process_vk + verify_with_processed_vk (reference src/zkey.rs:868-870,914-916) for a
+    batch under one key on the GPU (g16_verify_batch).  proofs: Proof objects or 256-byte strings;
+    public_inputs: one sequence of n_public values (ints or Montgomery rows) per proof.  Returns a
+    list of bools."""
+    lib = lib or B.load()
+    raw = b"".join(p.raw if isinstance(p, Proof) else bytes(p) for p in proofs)
+    n = len(raw) // B.G16_PROOF_BYTES
+    ic = np.ascontiguousarray(vk.gamma_abc_g1, dtype=np.uint8).reshape(-1, 64)
+    n_pub = ic.shape[0] - 1
+    if len(public_inputs) != n:
+        raise G16Error(B.G16_ERR_INVALID, "one public-input vector per proof")
+    flat = []
+    for pi in public_inputs:
+        if len(pi) != n_pub:
+            raise G16Error(B.G16_ERR_INVALID, "MalformedVerifyingKey: wrong number of public inputs")
+        flat.extend(pi)
+    pubs = _as_fr(flat, lib) if (flat and not isinstance(flat[0], np.ndarray)) else \
+        (np.ascontiguousarray(np.stack(flat)) if flat else np.zeros((0, 4), np.uint64))
+    d = B.VkDesc()
+    C.memmove(d.alpha_g1, bytes(vk.alpha_g1), 64)
+    C.memmove(d.beta_g2, bytes(vk.beta_g2), 128)
+    C.memmove(d.gamma_g2, bytes(vk.gamma_g2), 128)
+    C.memmove(d.delta_g2, bytes(vk.delta_g2), 128)
+    d.ic, d.ic_count = ic.ctypes.data, ic.shape[0]
+    buf = np.frombuffer(raw, dtype=np.uint8)
+    ok = np.zeros(max(n, 1), dtype=np.uint8)
+    st = lib.g16_verify_batch(device, C.byref(d), _np_ptr(buf), _np_ptr(pubs), n, _np_ptr(ok))
+    if st != B.G16_OK:
+        raise G16Error(st, "g16_verify_batch failed")
+    return [bool(x) for x in ok[:n]]
+
+
 class _Reduction:
     """R1CSToQAP::witness_map_from_matrices on the GPU; the subclass names the QAP."""
     NAME = "circom"
@@ -707,6 +740,11 @@ class Groth16:
                             device=device, lib=lib, reduction=reduction)
         pk.reduction = reduction
         return pk
+
+    @staticmethod
+    def verify(vk: "VerifyingKey", public_inputs, proof, **kw) -> bool:
+        """Groth16::verify_with_processed_vk(&process_vk(&vk), inputs, &proof) on the GPU"""
+        return verify_batch(vk, [proof], [list(public_inputs)], **kw)[0]
 
     @staticmethod
     def create_proof_with_reduction_and_matrices(pk: ProvingKey, r, s, matrices: ConstraintMatrices,

@@ -59,6 +59,11 @@ class Options(C.Structure):
                 ("reduction", C.c_int), ("reserved", C.c_int * 1)]
 
 
+class VkDesc(C.Structure):
+    _fields_ = [("alpha_g1", C.c_uint8 * 64), ("beta_g2", C.c_uint8 * 128), ("gamma_g2", C.c_uint8 * 128),
+                ("delta_g2", C.c_uint8 * 128), ("ic", C.c_void_p), ("ic_count", C.c_uint32)]
+
+
 class ZkeyHeader(C.Structure):
     _fields_ = [("n8q", C.c_uint32), ("n8r", C.c_uint32), ("q", C.c_uint8 * 32),
                 ("r", C.c_uint8 * 32), ("n_vars", C.c_uint32), ("n_public", C.c_uint32),
@@ -89,7 +94,7 @@ ABI_SYMBOLS = [
     "g16_prove_dist_phase3", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info",
     "g16_witness_buffer", "g16_witness_upload", "g16_witness_host_buffer", "g16_ctx_create_multi", "g16_dist_set_exchange_stream",
     "g16_partial_buffer", "g16_gather_buffer", "g16_prove_finish_dev", "g16_witness_map_dev", "g16_msm_g1_dev",
-    "g16_msm_g2_dev", "g16_debug_ntt", "g16_debug_alu_bench", "g16_check_satisfied", "g16_zkey_write",
+    "g16_msm_g2_dev", "g16_verify_batch", "g16_debug_ntt", "g16_debug_alu_bench", "g16_check_satisfied", "g16_zkey_write",
     "g16_setup_create", "g16_setup_create_ex", "g16_setup_destroy", "g16_setup_key",
     "g16_loader_last_error", "g16_zkey_open", "g16_zkey_open_mem", "g16_zkey_close",
     "g16_zkey_header_get", "g16_zkey_key", "g16_zkey_ic", "g16_zkey_matrices", "g16_r1cs_open",
@@ -144,6 +149,7 @@ class Library:
             "g16_ctx_info": (C.c_int, [vp, _u32p]),
             "g16_witness_buffer": (vp, [vp]),
             "g16_witness_host_buffer": (vp, [vp]),
+            "g16_verify_batch": (C.c_int, [C.c_int, C.POINTER(VkDesc), vp, vp, C.c_uint32, vp]),
             "g16_witness_upload": (C.c_int, [vp, vp, C.c_size_t]),
             "g16_witness_map_dev": (C.c_int, [vp, vp, C.c_size_t, vp]),
             "g16_msm_g1_dev": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),

@@ -1,0 +1,419 @@
+// verify.hip -- Groth16 batch verification on the GPU (first half).
+//
+// Replaces, for a batch of proofs under one verifying key,
+//   let pvk = Groth16::<Bn254>::process_vk(&params.vk)?;
+//   Groth16::<Bn254>::verify_with_processed_vk(&pvk, &inputs, &proof)?
+// (reference call sites src/zkey.rs:868-870,914-916; tests/groth16.rs:33-35): per proof
+//   e(A, B) * e(-alpha, beta) * e(-(IC_0 + sum_i pub_i IC_{i+1}), gamma) * e(-C, delta) == 1.
+// ark-groth16 / ark-ec are un-vendored, so this restates the published optimal-ate pairing for
+// BN254 the way the oracle does (oracle/bn254_ref.py:miller_loop) and is
+// pinned against it: Fq12 = Fq[w] / (w^12 - 18 w^6 + 82) in the polynomial basis, G2 arithmetic in
+// affine Fq2 on the twist, Miller loop over 6x + 2 followed by the two Frobenius steps.  The final
+// exponentiation is NOT the plain power of the oracle but the usual easy part
+// (q^6 - 1)(q^2 + 1) followed by the Fuentes-Castaneda hard part (three exponentiations by the BN
+// parameter x): it raises to a fixed multiple of (q^12 - 1) / r that is coprime to r, so
+// "result == 1" is the same predicate (checked against the oracle's plain power in the tests).
+//
+// Off the proving path and deliberately simple: ONE LANE PER PROOF, saturated-limb field.h
+// arithmetic, ~1.4 x 10^5 Fq multiplications per proof -- a throughput kernel for large batches,
+// not a latency win over one CPU core for a single proof.
+#include "../../include/g16_amd.h"
+
+#include <string.h>
+
+#include <memory>
+#include <mutex>
+
+#include "common.h"
+
+namespace g16 {
+
+struct F12 {
+  Fq c[12];  // coefficient of w^i
+};
+
+G16_HD F12 f12_one() {
+  F12 r;
+  r.c[0] = Fq::one();
+#pragma unroll 1
+  for (int i = 1; i < 12; ++i) r.c[i] = Fq::zero();
+  return r;
+}
+G16_HD bool f12_is_one(const F12& a) {
+  bool ok = a.c[0] == Fq::one();
+#pragma unroll 1
+  for (int i = 1; i < 12; ++i) ok = ok && a.c[i].is_zero();
+  return ok;
+}
+
+// schoolbook product, then w^k -> 18 w^(k-6) - 82 w^(k-12) from the top (oracle _f12_mul)
+G16_NOINLINE void f12_mul(F12* out, const F12* a, const F12* b) {
+  Fq t[23];
+#pragma unroll 1
+  for (int k = 0; k < 23; ++k) t[k] = Fq::zero();
+#pragma unroll 1
+  for (int i = 0; i < 12; ++i) {
+    const Fq ai = a->c[i];
+    if (ai.is_zero()) continue;  // the lines are sparse
+#pragma unroll 1
+    for (int j = 0; j < 12; ++j) t[i + j] = t[i + j] + ai * b->c[j];
+  }
+  const Fq c18 = Fq::from_u32(18), c82 = Fq::from_u32(82);
+#pragma unroll 1
+  for (int k = 22; k >= 12; --k) {
+    const Fq v = t[k];
+    t[k - 6] = t[k - 6] + c18 * v;
+    t[k - 12] = t[k - 12] - c82 * v;
+  }
+#pragma unroll 1
+  for (int i = 0; i < 12; ++i) out->c[i] = t[i];
+}
+
+// conjugation = Frobenius^6: w -> -w
+G16_HD F12 f12_conj(const F12& a) {
+  F12 r;
+#pragma unroll 1
+  for (int i = 0; i < 12; ++i) r.c[i] = (i & 1) ? a.c[i].neg() : a.c[i];
+  return r;
+}
+
+// Frobenius^k through the table tab[i] = (w^i)^(q^k): a(w)^(q^k) = sum a_i tab[i]  (a_i in Fq)
+G16_NOINLINE void f12_frob(F12* out, const F12* a, const F12* tab) {
+  F12 r;
+#pragma unroll 1
+  for (int j = 0; j < 12; ++j) r.c[j] = Fq::zero();
+#pragma unroll 1
+  for (int i = 0; i < 12; ++i) {
+    const Fq ai = a->c[i];
+#pragma unroll 1
+    for (int j = 0; j < 12; ++j) r.c[j] = r.c[j] + ai * tab[i].c[j];
+  }
+  *out = r;
+}
+
+struct VkDev {
+  G1Affine alpha_neg;            // -alpha
+  G2Affine beta, gamma, delta;
+  Fq2 frob_x, frob_y;            // xi^((q-1)/3), xi^((q-1)/2): Frobenius on the twist
+  Fq2 b_twist;                   // 3 / xi
+  F12 frob[3][12];               // frob[k-1][i] = (w^i)^(q^k), k = 1, 2, 3
+  F12 ml_alpha_beta;             // Miller loop of (beta, -alpha): the same for every proof
+};
+
+// a^-1 = (product of the 11 other conjugates) / norm
+G16_NOINLINE void f12_inv(F12* out, const F12* a, const VkDev* vk) {
+  F12 f = *a, c = f12_one();
+#pragma unroll 1
+  for (int i = 0; i < 11; ++i) {
+    f12_frob(&f, &f, vk->frob[0]);
+    f12_mul(&c, &c, &f);
+  }
+  F12 n;
+  f12_mul(&n, a, &c);  // in Fq: only c[0] is non-zero
+  const Fq ni = n.c[0].inv();
+#pragma unroll 1
+  for (int i = 0; i < 12; ++i) out->c[i] = c.c[i] * ni;
+}
+
+// conj(a^x), x = 4965661367192848881 (the BN254 parameter): "exp_by_neg_x" of ark-ec's BN template
+G16_NOINLINE void f12_exp_neg_x(F12* out, const F12* a) {
+  const uint64_t X = 4965661367192848881ull;
+  F12 r = f12_one();
+#pragma unroll 1
+  for (int bit = 62; bit >= 0; --bit) {
+    f12_mul(&r, &r, &r);
+    if ((X >> bit) & 1) f12_mul(&r, &r, a);
+  }
+  *out = f12_conj(r);
+}
+
+G16_NOINLINE bool final_exp_is_one(const F12* f, const VkDev* vk) {
+  // easy part: f^((q^6 - 1)(q^2 + 1))
+  F12 fi, r, t;
+  f12_inv(&fi, f, vk);
+  F12 fc = f12_conj(*f);
+  f12_mul(&r, &fc, &fi);
+  f12_frob(&t, &r, vk->frob[1]);
+  f12_mul(&r, &t, &r);
+  // hard part (Fuentes-Castaneda et al., as in ark-ec's bn::final_exponentiation)
+  F12 y0, y1, y2, y3, y4, y5, y6, y7, y8, y9, y10, y11, y12, y13, y14, y15;
+  f12_exp_neg_x(&y0, &r);
+  f12_mul(&y1, &y0, &y0);
+  f12_mul(&y2, &y1, &y1);
+  f12_mul(&y3, &y2, &y1);
+  f12_exp_neg_x(&y4, &y3);
+  f12_mul(&y5, &y4, &y4);
+  f12_exp_neg_x(&y6, &y5);
+  y3 = f12_conj(y3);
+  y6 = f12_conj(y6);
+  f12_mul(&y7, &y6, &y4);
+  f12_mul(&y8, &y7, &y3);
+  f12_mul(&y9, &y8, &y1);
+  f12_mul(&y10, &y8, &y4);
+  f12_mul(&y11, &y10, &r);
+  f12_frob(&y12, &y9, vk->frob[0]);
+  f12_mul(&y13, &y12, &y11);
+  f12_frob(&y8, &y8, vk->frob[1]);
+  f12_mul(&y14, &y8, &y13);
+  r = f12_conj(r);
+  f12_mul(&y15, &r, &y9);
+  f12_frob(&y15, &y15, vk->frob[2]);
+  f12_mul(&t, &y15, &y14);
+  return f12_is_one(t);
+}
+
+// a + b i in Fq2 -> (a - 9 b) + b w^6, added (sign = +-1) at w^shift   (oracle _embed)
+G16_HD void embed(F12& l, const Fq2& z, int shift, bool negate) {
+  Fq nine_b = z.c1.dbl().dbl().dbl() + z.c1;
+  Fq lo = z.c0 - nine_b, hi = z.c1;
+  if (negate) {
+    lo = lo.neg();
+    hi = hi.neg();
+  }
+  l.c[shift] = l.c[shift] + lo;
+  l.c[shift + 6] = l.c[shift + 6] + hi;
+}
+
+// line through the twisted points T, Q evaluated at P; T <- T + Q   (oracle _line)
+G16_NOINLINE void line(F12* l_out, G2Affine* T, const G2Affine* Qp, const G1Affine* P, bool* t_inf) {
+  F12 l;
+#pragma unroll 1
+  for (int i = 0; i < 12; ++i) l.c[i] = Fq::zero();
+  if (*t_inf) {  // T at infinity (degenerate inputs only): the line is 1, T + Q = Q
+    *l_out = f12_one();
+    *T = *Qp;
+    *t_inf = false;
+    return;
+  }
+  const bool same_x = T->x == Qp->x;
+  if (same_x && T->y != Qp->y) {  // vertical
+    l.c[0] = P->x;
+    embed(l, T->x, 2, true);
+    *l_out = l;
+    *t_inf = true;
+    return;
+  }
+  Fq2 m;
+  if (same_x) {  // tangent: 3 x^2 / (2 y)
+    Fq2 x2 = T->x.sqr();
+    m = (x2.dbl() + x2) * T->y.dbl().inv();
+  } else {
+    m = (Qp->y - T->y) * (Qp->x - T->x).inv();
+  }
+  const Fq2 x3 = m.sqr() - T->x - Qp->x;
+  const Fq2 y3 = m * (T->x - x3) - T->y;
+  l.c[0] = P->y.neg();
+  embed(l, Fq2{m.c0 * P->x, m.c1 * P->x}, 1, false);
+  embed(l, T->y - m * T->x, 3, false);
+  T->x = x3;
+  T->y = y3;
+  *l_out = l;
+}
+
+G16_HD G2Affine frob_g2(const G2Affine& q, const VkDev* vk) {
+  return G2Affine{Fq2{q.x.c0, q.x.c1.neg()} * vk->frob_x, Fq2{q.y.c0, q.y.c1.neg()} * vk->frob_y};
+}
+
+// f *= ML(Q, P)   (oracle miller_loop; infinity on either side contributes 1)
+G16_NOINLINE void miller_mul(F12* f_io, const G2Affine* Qp, const G1Affine* P, const VkDev* vk) {
+  if (Qp->is_inf() || P->is_inf()) return;
+  const unsigned __int128 ATE = ((unsigned __int128)1 << 64) | 0x9d797039be763ba8ull;  // 6x + 2 = 29793968203157093288
+  F12 f = f12_one(), l;
+  G2Affine T = *Qp;
+  bool t_inf = false;
+#pragma unroll 1
+  for (int i = 63; i >= 0; --i) {  // bit_length(6x + 2) = 65: from the second-highest bit down
+    line(&l, &T, &T, P, &t_inf);
+    f12_mul(&f, &f, &f);
+    f12_mul(&f, &f, &l);
+    if ((ATE >> i) & 1) {
+      line(&l, &T, Qp, P, &t_inf);
+      f12_mul(&f, &f, &l);
+    }
+  }
+  const G2Affine q1 = frob_g2(*Qp, vk);
+  G2Affine q2 = frob_g2(q1, vk);
+  q2.y = q2.y.neg();
+  line(&l, &T, &q1, P, &t_inf);
+  f12_mul(&f, &f, &l);
+  line(&l, &T, &q2, P, &t_inf);
+  f12_mul(&f, &f, &l);
+  f12_mul(f_io, f_io, &f);
+}
+
+G16_HD bool on_curve_g1(const G1Affine& p) {
+  if (p.is_inf()) return true;
+  return p.y.sqr() == p.x.sqr() * p.x + Fq::from_u32(3);
+}
+G16_HD bool on_curve_g2(const G2Affine& p, const VkDev* vk) {
+  if (p.is_inf()) return true;
+  return p.y.sqr() == p.x.sqr() * p.x + vk->b_twist;
+}
+
+namespace {
+
+__global__ void k_verify_prepare(VkDev* vk) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  F12 f = f12_one();
+  miller_mul(&f, &vk->beta, &vk->alpha_neg, vk);
+  vk->ml_alpha_beta = f;
+}
+
+// one lane per proof
+__global__ void __launch_bounds__(64) k_verify_batch(const VkDev* vk, const G1Affine* ic, uint32_t n_pub,
+                                                     const uint8_t* proofs, const Fr* pubs, uint32_t n,
+                                                     uint8_t* ok) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine A, C;
+  G2Affine B;
+  memcpy(&A, proofs + (size_t)i * G16_PROOF_BYTES, 64);
+  memcpy(&B, proofs + (size_t)i * G16_PROOF_BYTES + 64, 128);
+  memcpy(&C, proofs + (size_t)i * G16_PROOF_BYTES + 192, 64);
+  if (!(on_curve_g1(A) && on_curve_g1(C) && on_curve_g2(B, vk))) {
+    ok[i] = 0;
+    return;
+  }
+  // prepared inputs: IC_0 + sum_j pub_j IC_{j+1}   (ark-groth16 prepare_inputs)
+  XYZZ<Fq> acc = XYZZ<Fq>::from_affine(ic[0]);
+#pragma unroll 1
+  for (uint32_t j = 0; j < n_pub; ++j) {
+    const U256 s = pubs[(size_t)i * n_pub + j].to_canonical();
+    XYZZ<Fq> t = XYZZ<Fq>::from_affine(ic[j + 1]).mul(s);
+    acc.add(t);
+  }
+  G1Affine vkx = acc.to_affine().neg();
+  G1Affine Cn = C.neg();
+  F12 f = vk->ml_alpha_beta;
+  miller_mul(&f, &B, &A, vk);
+  miller_mul(&f, &vk->gamma, &vkx, vk);
+  miller_mul(&f, &vk->delta, &Cn, vk);
+  ok[i] = final_exp_is_one(&f, vk) ? 1 : 0;
+}
+
+// ---- host-side constants (the same field classes compile for the host) ------------------------
+void words_of_modulus(uint32_t (&w)[8]) {
+  for (int i = 0; i < 8; ++i) w[i] = FqParams::MOD[i];
+}
+// e <- (e - sub) / div for small sub, div (exact)
+void small_sub_div(uint32_t (&e)[8], uint32_t sub, uint32_t div) {
+  uint64_t br = sub;
+  for (int i = 0; i < 8 && br; ++i) {
+    const uint64_t d = (uint64_t)e[i] - br;
+    e[i] = (uint32_t)d;
+    br = (d >> 63) & 1;
+  }
+  uint64_t rem = 0;
+  for (int i = 7; i >= 0; --i) {
+    const uint64_t cur = (rem << 32) | e[i];
+    e[i] = (uint32_t)(cur / div);
+    rem = cur % div;
+  }
+}
+Fq2 fq2_pow(Fq2 a, const uint32_t (&e)[8]) {
+  Fq2 r = Fq2::one();
+  for (int i = 255; i >= 0; --i) {
+    r = r.sqr();
+    if ((e[i >> 5] >> (i & 31)) & 1) r = r * a;
+  }
+  return r;
+}
+F12 f12_pow_q(const F12& a) {
+  uint32_t q[8];
+  words_of_modulus(q);
+  F12 r = f12_one();
+  for (int i = 255; i >= 0; --i) {
+    f12_mul(&r, &r, &r);
+    if ((q[i >> 5] >> (i & 31)) & 1) f12_mul(&r, &r, &a);
+  }
+  return r;
+}
+
+struct HostConsts {
+  Fq2 frob_x, frob_y, b_twist;
+  F12 frob[3][12];
+};
+const HostConsts& host_consts() {
+  static HostConsts H;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const Fq2 xi{Fq::from_u32(9), Fq::one()};
+    uint32_t e[8];
+    words_of_modulus(e);
+    small_sub_div(e, 1, 3);
+    H.frob_x = fq2_pow(xi, e);
+    words_of_modulus(e);
+    small_sub_div(e, 1, 2);
+    H.frob_y = fq2_pow(xi, e);
+    const Fq2 three{Fq::from_u32(3), Fq::zero()};
+    H.b_twist = three * xi.inv();
+    F12 w = f12_one();
+    w.c[0] = Fq::zero();
+    w.c[1] = Fq::one();
+    F12 wk = w;
+    for (int k = 0; k < 3; ++k) {
+      wk = f12_pow_q(wk);  // w^(q^(k+1))
+      H.frob[k][0] = f12_one();
+      for (int i = 1; i < 12; ++i) f12_mul(&H.frob[k][i], &H.frob[k][i - 1], &wk);
+    }
+  });
+  return H;
+}
+
+}  // namespace
+}  // namespace g16
+
+using namespace g16;
+
+extern "C" g16_status g16_verify_batch(int device, const g16_vk_desc* vk, const uint8_t* proofs,
+                                       const uint64_t* public_inputs, uint32_t n_proofs,
+                                       uint8_t* ok_out) {
+  if (!vk || !vk->ic || vk->ic_count < 1 || (n_proofs && (!proofs || !ok_out))) return G16_ERR_INVALID;
+  const uint32_t n_pub = vk->ic_count - 1;
+  if (n_proofs && n_pub && !public_inputs) return G16_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return G16_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return G16_ERR_INVALID;
+  if (!n_proofs) return G16_OK;
+  try {
+    G16_HIP(hipSetDevice(device));
+    const HostConsts& H = host_consts();
+    VkDev* hv = new VkDev();
+    std::unique_ptr<VkDev> keep(hv);
+    G1Affine alpha;
+    memcpy(&alpha, vk->alpha_g1, 64);
+    hv->alpha_neg = alpha.neg();
+    memcpy(&hv->beta, vk->beta_g2, 128);
+    memcpy(&hv->gamma, vk->gamma_g2, 128);
+    memcpy(&hv->delta, vk->delta_g2, 128);
+    hv->frob_x = H.frob_x;
+    hv->frob_y = H.frob_y;
+    hv->b_twist = H.b_twist;
+    memcpy(hv->frob, H.frob, sizeof H.frob);
+    DevBuf<VkDev> dvk;
+    DevBuf<G1Affine> dic;
+    DevBuf<uint8_t> dproofs, dok;
+    DevBuf<Fr> dpub;
+    dvk.alloc(1);
+    dic.alloc(vk->ic_count);
+    dproofs.alloc((size_t)n_proofs * G16_PROOF_BYTES);
+    dok.alloc(n_proofs);
+    dpub.alloc((size_t)n_proofs * (n_pub ? n_pub : 1));
+    G16_HIP(hipMemcpy(dvk.p, hv, sizeof(VkDev), hipMemcpyHostToDevice));
+    G16_HIP(hipMemcpy(dic.p, vk->ic, (size_t)vk->ic_count * 64, hipMemcpyHostToDevice));
+    G16_HIP(hipMemcpy(dproofs.p, proofs, (size_t)n_proofs * G16_PROOF_BYTES, hipMemcpyHostToDevice));
+    if (n_pub)
+      G16_HIP(hipMemcpy(dpub.p, public_inputs, (size_t)n_proofs * n_pub * 32, hipMemcpyHostToDevice));
+    G16_LAUNCH(k_verify_prepare, 1, 64, 0, nullptr, dvk.p);
+    G16_LAUNCH(k_verify_batch, ceil_div(n_proofs, 64), 64, 0, nullptr, (const VkDev*)dvk.p,
+               (const G1Affine*)dic.p, n_pub, (const uint8_t*)dproofs.p, (const Fr*)dpub.p, n_proofs,
+               dok.p);
+    G16_HIP(hipDeviceSynchronize());
+    G16_HIP(hipMemcpy(ok_out, dok.p, n_proofs, hipMemcpyDeviceToHost));
+    return G16_OK;
+  } catch (const HipError&) {
+    return G16_ERR_HIP;
+  } catch (const std::exception&) {
+    return G16_ERR_INTERNAL;
+  }
+}

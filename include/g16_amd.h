@@ -219,6 +219,23 @@ g16_status g16_check_satisfied(int device, const g16_csr* a, const g16_csr* b, c
                                uint32_t num_constraints, const uint64_t* w, size_t n_vars,
                                int64_t* first_unsatisfied);
 
+/* ---- batch verification (not on the proving path) --------------- */
+/* VerifyingKey<Bn254> in the packed forms read_zkey produces (src/zkey.rs:241-257): ic =
+ * gamma_abc_g1, ic_count = n_public + 1 points of 64 bytes.                                        */
+typedef struct {
+  uint8_t alpha_g1[64];
+  uint8_t beta_g2[128], gamma_g2[128], delta_g2[128];
+  const uint8_t* ic;
+  uint32_t ic_count;
+} g16_vk_desc;
+/* Groth16::process_vk + verify_with_processed_vk (reference call sites src/zkey.rs:868-870,914-916;
+ * tests/groth16.rs:33-35) for n_proofs proofs under one key, one GPU lane per proof:
+ *   ok_out[i] = 1 iff e(A_i, B_i) = e(alpha, beta) e(IC_0 + sum_j pub_ij IC_{j+1}, gamma) e(C_i, delta)
+ * proofs: n_proofs x G16_PROOF_BYTES (A | B | C as g16_prove writes them); public_inputs:
+ * n_proofs x (ic_count - 1) x 4 u64 Montgomery Fr.  Points off their curve give 0.                */
+g16_status g16_verify_batch(int device, const g16_vk_desc* vk, const uint8_t* proofs,
+                            const uint64_t* public_inputs, uint32_t n_proofs, uint8_t* ok_out);
+
 /* ---- debug / parity entry points (tests) ----------------------------------------------------- */
 /* In-place size-2^log_n NTT of host data, natural order in and out (ark-poly fft_in_place /
  * ifft_in_place semantics).  algo 0: DIF kernels + bit-reversal; algo 1: bit-reversal + DIT

@@ -82,6 +82,17 @@ pub struct g16_options {
 
 #[repr(C)]
 #[derive(Clone, Copy)]
+pub struct g16_vk_desc {
+    pub alpha_g1: [u8; 64],
+    pub beta_g2: [u8; 128],
+    pub gamma_g2: [u8; 128],
+    pub delta_g2: [u8; 128],
+    pub ic: *const u8,
+    pub ic_count: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
 pub struct g16_zkey_header {
     pub n8q: u32,
     pub n8r: u32,
@@ -161,6 +172,7 @@ extern "C" {
     pub fn g16_witness_upload(ctx: *mut g16_ctx, w: *const u64, n_vars: usize) -> g16_status;
     pub fn g16_witness_host_buffer(ctx: *mut g16_ctx) -> *mut c_void;
     pub fn g16_check_satisfied(device: c_int, a: *const g16_csr, b: *const g16_csr, c: *const g16_csr, num_constraints: u32, w: *const u64, n_vars: usize, first_unsatisfied: *mut i64) -> g16_status;
+    pub fn g16_verify_batch(device: c_int, vk: *const g16_vk_desc, proofs: *const u8, public_inputs: *const u64, n_proofs: u32, ok_out: *mut u8) -> g16_status;
     pub fn g16_debug_ntt(device: c_int, data: *mut u64, log_n: c_int, inverse: c_int, algo: c_int) -> g16_status;
     pub fn g16_debug_alu_bench(device: c_int, kind: c_int, blocks: u32, iters: u32, seconds: *mut c_double, ops: *mut c_double) -> g16_status;
     pub fn g16_setup_create(device: c_int, at: *const g16_csr, bt: *const g16_csr, ct: *const g16_csr, n_vars: u32, n_public: u32, num_constraints: u32, toxic: *const u64, out: *mut *mut g16_setup) -> g16_status;

@@ -72,7 +72,7 @@ def _rust_struct_fields(name):
 
 
 def test_repr_c_structs_match_the_headers():
-    for name in ("g16_csr", "g16_key_desc", "g16_options", "g16_zkey_header", "g16_matrices", "g16_r1cs_header"):
+    for name in ("g16_csr", "g16_key_desc", "g16_options", "g16_vk_desc", "g16_zkey_header", "g16_matrices", "g16_r1cs_header"):
         assert _rust_struct_fields(name) == _c_struct_fields(name), name
 
 
