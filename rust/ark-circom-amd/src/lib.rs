@@ -21,10 +21,12 @@ pub mod ffi;
 pub mod pack;
 mod prover;
 mod reduction;
+mod verify;
 
 pub use ark_circom::{circom, read_zkey, CircomBuilder, CircomCircuit, CircomConfig, CircomReduction, Wasm, WitnessCalculator};
 pub use prover::{GpuError, GpuProver, Reduction};
 pub use reduction::GpuCircomReduction;
+pub use verify::verify_batch;
 
 use ark_bn254::{Bn254, Fr};
 use ark_groth16::Proof;

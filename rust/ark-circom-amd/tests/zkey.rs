@@ -65,4 +65,9 @@ async fn verify_proof_with_zkey_without_r1cs() {
     let inputs = &full_assignment[1..num_inputs];
     let verified = Groth16::<Bn254>::verify_with_processed_vk(&pvk, inputs, &proof).unwrap();
     assert!(verified);
+
+    // the GPU batch verifier gives the same verdicts (right input, wrong input)
+    let wrong = vec![inputs[0] + Fr::from(1u64)];
+    let ok = ark_circom_amd::verify_batch(&params.vk, &[inputs.to_vec(), wrong], &[proof.clone(), proof], 0).unwrap();
+    assert_eq!(ok, vec![true, false]);
 }
