@@ -231,6 +231,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL's internal stream with high priority: a normal-priority stream would share a hardware
+        # queue with the ctx's MSM streams and the all-to-all would run behind them
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if mode == "ranks" and backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
