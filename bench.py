@@ -22,6 +22,8 @@ N > 1 (strong scaling of ONE proof): MSMs sharded by point range, witness map di
   mode "ranks"       (G16_BENCH_MODE=ranks, or fewer visible devices than ranks): one ctx per
                      process, RCCL all_to_all / all_gather on a torch stream the library orders
                      itself against with events (g16_dist_set_exchange_stream): no host syncs.
+                     Under torch.distributed.run it is also the fallback when the in-library ctx
+                     cannot be built or its first proof does not verify (`fallback_reason`).
 
 Other workloads / modes (BASELINE configs 2 and 5, the reference's own bench circuit):
   --workload dense-skewed   3-term A rows / 2-term B rows, >= 50 % of the witness in {0, 1}, key
@@ -187,6 +189,52 @@ def complex_circuit(cc):
 
 
 # ------------------------------------------------------------------------------------------------
+def setup_prover(cc, torch, args, mode, rank, local_rank, n_gpus, world, one_gpu, A, B, Cm, n_vars, tox,
+                 mats, w, rs, w_ints):
+    """Key + ctx + resident witness for one launch mode.  Returns (active, pk, mats, m, prover, w_dev,
+    w_ptr, zkey_path); pk is None on ranks that do not prove (in-library mode: every rank but 0)."""
+    active = mode != "inlib" or rank == 0     # ranks that prove (idle ranks never touch a GPU)
+    if not active:
+        return False, None, None, None, None, None, None, None
+    torch.cuda.set_device(local_rank if mode != "inlib" else (0 if not one_gpu else local_rank))
+    dev0 = local_rank if mode != "inlib" else (local_rank if one_gpu else 0)
+    pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox, device=dev0)
+    zkey_path = None
+    if args.workload != "chain":
+        # through the file format: snarkjs-layout .zkey written, mapped and parsed back (read_zkey)
+        import tempfile
+        zkey_path = os.path.join(tempfile.gettempdir(), f"g16_bench_{os.getpid()}.zkey")
+        cc.write_zkey(zkey_path, pk, mats)
+        pk, mats = cc.read_zkey(zkey_path)
+    kw = dict(window_bits=args.window_bits, planes=args.planes)
+    if mode == "single":
+        prover = cc.Prover(pk, mats, device=local_rank, **kw)
+    elif mode == "inlib":
+        if os.environ.get("G16_BENCH_FAIL_INLIB"):   # exercises the fallback on a 1-GPU box
+            raise RuntimeError("G16_BENCH_FAIL_INLIB is set")
+        devices = [dev0] * n_gpus if one_gpu else list(range(n_gpus))
+        prover = cc.Prover(pk, mats, devices=devices, **kw)
+    else:
+        dist_wm = os.environ.get("G16_BENCH_DIST_WM", "1") != "0"
+        prover = cc.Prover(pk, mats, device=local_rank, rank=rank, world=world, dist_wm=dist_wm, **kw)
+    w_dev = None
+    if mode == "inlib":
+        # resident on EVERY device before the timed region, as at N = 1 (g16_witness_upload): the ctx
+        # would otherwise peer-broadcast 32 N bytes from the first device inside every proof
+        w_ptr = prover.upload_witness(w)
+        if world > 1:
+            # first proof of a path no 1-GPU box can exercise: it has to verify (GPU verifier; the
+            # checker legs below still run on the timed proof) or the per-rank path takes over
+            trial = prover.prove_dev(rs[0], rs[1], w_ptr)
+            if not cc.verify_batch(pk.vk, [trial], [[w_ints[1]]], device=dev0)[0]:
+                prover.close()
+                raise RuntimeError("the first in-library proof does not verify")
+    else:
+        w_dev = torch.from_numpy(w.view(np.int64)).to(f"cuda:{torch.cuda.current_device()}")
+        w_ptr = w_dev.data_ptr()
+    return True, pk, mats, mats.num_constraints, prover, w_dev, w_ptr, zkey_path
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,9 +271,6 @@ def main():
         raise SystemExit("mode 'ranks' needs torch.distributed.run with one process per GPU")
     if one_gpu:
         local_rank = int(os.environ.get("G16_BENCH_DEVICE", 0))
-    active = mode != "inlib" or rank == 0     # ranks that prove (idle ranks never touch a GPU)
-    if active:
-        torch.cuda.set_device(local_rank if mode != "inlib" else (0 if not one_gpu else local_rank))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -273,35 +318,42 @@ def main():
     rs = cc.fr_from_ints([r, s])
     w = cc.fr_from_ints(w_ints)
 
-    pk = prover = None
-    if active:
-        dev0 = local_rank if mode != "inlib" else (local_rank if one_gpu else 0)
-        pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox, device=dev0)
-        if args.workload != "chain":
-            # through the file format: snarkjs-layout .zkey written, mapped and parsed back (read_zkey)
-            import tempfile
-            zkey_path = os.path.join(tempfile.gettempdir(), f"g16_bench_{os.getpid()}.zkey")
-            cc.write_zkey(zkey_path, pk, mats)
-            pk, mats = cc.read_zkey(zkey_path)
-            m = mats.num_constraints
-        kw = dict(window_bits=args.window_bits, planes=args.planes)
-        if mode == "single":
-            prover = cc.Prover(pk, mats, device=local_rank, **kw)
-        elif mode == "inlib":
-            devices = [dev0] * n_gpus if one_gpu else list(range(n_gpus))
-            prover = cc.Prover(pk, mats, devices=devices, **kw)
-        else:
-            dist_wm = os.environ.get("G16_BENCH_DIST_WM", "1") != "0"
-            prover = cc.Prover(pk, mats, device=local_rank, rank=rank, world=world, dist_wm=dist_wm, **kw)
+    # Under torch.distributed.run the in-library ctx is tried first (rank 0 drives every device); if
+    # it cannot be built or its first proof does not verify, every rank falls back to its own ctx
+    # with RCCL collectives in between -- the line then says so (config.parallelism, fallback_reason).
+    pg_nccl = mode == "ranks" and backend == "nccl"   # the default process group lives on the GPUs
+    grp = None                                        # RCCL group of the fallback (default group: gloo)
+    fallback_reason = None
+    while True:
+        trial = mode == "inlib" and world > 1
+        try:
+            (active, pk_, mats_, m_, prover, w_dev, w_ptr, zkey_path) = setup_prover(
+                cc, torch, args, mode, rank, local_rank, n_gpus, world, one_gpu, A, B, Cm, n_vars, tox,
+                mats, w, rs, w_ints)
+            ok, why = True, ""
+        except Exception as e:  # noqa: BLE001 -- anything the trial throws selects the fallback
+            if not trial:
+                raise
+            ok, why = False, f"{type(e).__name__}: {e}"
+        if trial:
+            flag = [ok, why]
+            dist.broadcast_object_list(flag, src=0)
+            ok, why = flag
+            if not ok:
+                if rank == 0:
+                    print(f"bench.py: in-library multi-device ctx failed ({why}); falling back to one "
+                          "ctx per process with RCCL collectives", file=sys.stderr)
+                fallback_reason, mode = why, "ranks"
+                import gc
+                gc.collect()                      # a half-built in-library ctx frees its HBM here
+                if backend == "nccl":
+                    torch.cuda.set_device(local_rank)
+                    grp = dist.new_group(backend="nccl")
+                continue
+        break
+    if pk_ is not None:
+        pk, mats, m = pk_, mats_, m_
     dev = f"cuda:{torch.cuda.current_device()}" if active else "cpu"
-    w_dev = w_ptr = None
-    if active and mode == "inlib":
-        # resident on EVERY device before the timed region, as at N = 1 (g16_witness_upload): the ctx
-        # would otherwise peer-broadcast 32 N bytes from the first device inside every proof
-        w_ptr = prover.upload_witness(w)
-    elif active:
-        w_dev = torch.from_numpy(w.view(np.int64)).to(dev)
-        w_ptr = w_dev.data_ptr()
     if active:
         torch.cuda.synchronize()
     t_setup = time.time() - t_setup
@@ -321,7 +373,7 @@ def main():
         def exchange():
             with torch.cuda.stream(xs):
                 if backend == "nccl":
-                    dist.all_to_all_single(recv, send)
+                    dist.all_to_all_single(recv, send, group=grp)
                 else:
                     xs.synchronize()
                     hs, hr = send.cpu(), torch.empty(nbytes, dtype=torch.uint8)
@@ -331,7 +383,7 @@ def main():
         def gather():
             with torch.cuda.stream(xs):
                 if backend == "nccl":
-                    dist.all_gather_into_tensor(gath_t, part_t)
+                    dist.all_gather_into_tensor(gath_t, part_t, group=grp)
                 else:
                     xs.synchronize()
                     parts = [torch.empty(1024, dtype=torch.uint8) for _ in range(world)]
@@ -375,7 +427,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=dev if (mode == "ranks" and backend == "nccl") else "cpu")
+                         device=dev if pg_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if not active or rank != 0:
@@ -541,6 +593,8 @@ def main():
         par = (f"msm-point-range-shard x{n_gpus} + four-step witness map (2 all-to-all), "
                + ("one g16_ctx_create_multi ctx in one process: peer copies over xGMI inside the library"
                   if mode == "inlib" else "one process per GPU: RCCL all_to_all / all_gather, event hand-offs"))
+        if fallback_reason:
+            par += " [fallback: the in-library ctx failed on this node]"
         if one_gpu:
             par += " [functional run: every rank on ONE GPU]"
     out = {
@@ -563,6 +617,8 @@ def main():
                                "-> 256 B D2H; `value` keeps the witness resident in HBM (bench contract)",
         "library": lib_path,
     }
+    if fallback_reason:
+        out["fallback_reason"] = fallback_reason
     if parts:
         out["parts_ms"] = parts
     if cpu:
