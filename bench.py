@@ -556,32 +556,49 @@ def main():
                         "host_cpu_count": os.cpu_count()})
 
     # ---------------- roofline of the dominant kernel (k_bucket_accumulate<Fq>) ----------------
+    # G1 accumulation launches of a proof: ONE over the interleaved A|B1 pair (its own stage) and one
+    # each for L and H -- the single-query launches are the roofline's kernel, the pair is beside it
     acc_ms, acc_cnt = stages["msm_accumulate_g1"]
+    pair_ms, pair_cnt = stages.get("msm_accumulate_g1_pair", (0.0, 0))
     per_launch_ms = acc_ms / max(acc_cnt, 1)
     # one G1 MSM of length L = 96 L algorithmic bytes (64 B point + 32 B scalar)
     shard_w, shard_h = info["shard_w"], info["shard_h"]
-    avg_len = (3 * shard_w + shard_h) / 4.0          # launches per step: A, B1, L (witness) and H
+    W_w, W_h = info["W_w"], info["W_h"]
+    if pair_cnt:
+        avg_len = (shard_w + shard_h) / 2.0                      # L and H
+        madds = (shard_w * W_w + shard_h * W_h) / 2.0
+    else:                                                        # G16_NO_PAIR_AB=1: A, B1, L and H
+        avg_len = (3 * shard_w + shard_h) / 4.0
+        madds = (3 * shard_w * W_w + shard_h * W_h) / 4.0        # mixed additions per launch (upper bound)
     alg_bytes = 96.0 * avg_len
     achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-    traffic = None
+    traffic = pair_traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if n_gpus == 1 and os.path.exists(tpath) and args.workload == "chain":
         t = json.load(open(tpath))
         if t.get("log2_domain") == k:
             traffic = t["traffic_bytes_per_launch"]
-    roofline = {"bound": "hbm", "kernel": "k_bucket_accumulate<Fq>", "achieved": achieved,
+            pair_traffic = t.get("pair_traffic_bytes_per_launch")
+    kname = "k_bucket_accumulate<Fq, 1, false>" if pair_cnt else "k_bucket_accumulate<Fq>"
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_unit": "bytes per launch (PMC: profiles/pmc_traffic.json)",
                 "avg_launch_ms": per_launch_ms, "launches_per_step": acc_cnt / args.steps,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "the kernel is integer-ALU bound (254-bit Montgomery arithmetic on v_mad_i64_i32), "
                         "not HBM bound: see `alu` and DESIGN.md section 4-5"}
+    if pair_cnt:
+        pms = pair_ms / pair_cnt
+        pbytes = (64.0 + 64.0 + 32.0) * shard_w      # two points + the scalar they share
+        roofline["pair_launch"] = {
+            "kernel": "k_bucket_accumulate<Fq, 2, true>", "what": "A and B1 over the interleaved A_i|B1_i records",
+            "avg_launch_ms": pms, "launches_per_step": pair_cnt / args.steps,
+            "algorithmic_bytes_per_launch": pbytes, "achieved": pbytes / (pms * 1e-3) / 1e9,
+            "frac": pbytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pair_traffic}
     # supplementary: the same launches against the micro-benchmarked integer multiply-add issue peak
-    W_w, W_h = info["W_w"], info["W_h"]
-    madds = (3 * shard_w * W_w + shard_h * W_h) / 4.0          # mixed additions per launch (upper bound)
     VMAD_PER_MADD = 1557.0                                     # 8 products + 2 squarings on 9x29-bit limbs
     VMAD_PEAK = 30.1e12                                        # profiles/r01_instr_rates.txt
-    alu = {"kernel": "k_bucket_accumulate<Fq>", "mixed_additions_per_s": madds / (per_launch_ms * 1e-3),
+    alu = {"kernel": kname, "mixed_additions_per_s": madds / (per_launch_ms * 1e-3),
            "vmad_per_s": madds * VMAD_PER_MADD / (per_launch_ms * 1e-3), "vmad_peak_per_s": VMAD_PEAK,
            "frac": madds * VMAD_PER_MADD / (per_launch_ms * 1e-3) / VMAD_PEAK,
            "alu_only_ceiling_mixed_additions_per_s": 16.7e9}

@@ -71,6 +71,16 @@ void collect_times(g16_ctx* c) {
   if (c->timer.enabled) c->timer.collect(c->st_ms, c->st_cnt);
 }
 
+// A and B1 accumulations into work1 slots 0 and 1: one launch over the interleaved pair, or two
+void accumulate_ab(g16_ctx* c, hipStream_t s, StageTimer* tm) {
+  if (c->ptsA.stride == 2) {
+    msm_accumulate_pair<Fq>(c->sort_w, c->ptsA, c->ptsB1, c->work1, 0, s, tm);
+  } else {
+    msm_accumulate<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, s, tm);
+    msm_accumulate<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, s, tm);
+  }
+}
+
 // main stream: witness-scalar sort, then the A, B1, L, B2 MSMs (ALU bound).  `after_ab` is called
 // once the A and B1 sums are enqueued: the provers fork the variable-base part of the
 // finalisation onto the side stream there.
@@ -101,8 +111,7 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     // 2^18 5.25 / 5.06, 2^19 8.03 / 7.46, 2^20 13.46 / 12.49, 2^21 23.1 / 23.1 (larger sets: the
     // reductions take issue slots from a saturated accumulation).
     hipStream_t q = c->red;
-    msm_accumulate<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, s, tm);
-    msm_accumulate<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, s, tm);
+    accumulate_ab(c, s, tm);
     G16_HIP(hipEventRecord(c->ev_acc[0], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[0], 0));
     msm_reduce<Fq>(c->sort_w, c->work1, 0, 2, &S->A, q, tm);
@@ -126,8 +135,7 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     // few buckets the reduction is pure latency (~0.4 ms of dependent EC additions whatever the
     // size): paying it once instead of three times is worth 20 % of a 2^16 proof and of a rank's
     // share of a sharded 2^22 proof.  ProofSums keeps A, B1, L adjacent.
-    msm_accumulate<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, s, tm);
-    msm_accumulate<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, s, tm);
+    accumulate_ab(c, s, tm);
     msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm);
     msm_reduce<Fq>(c->sort_w, c->work1, 0, 3, &S->A, s, tm);
     after_ab(s);
@@ -135,8 +143,8 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     // large bucket sets: the reduction is throughput bound, and reducing A and B1 at once lets
     // the variable-base part of the finalisation start ~10 ms earlier (measured at 2^22: 41.3 vs
     // 43.0 ms per proof)
-    msm_run<Fq>(c->sort_w, c->ptsA, 0, c->work1, &S->A, s, tm);
-    msm_run<Fq>(c->sort_w, c->ptsB1, 0, c->work1, &S->B1, s, tm);
+    accumulate_ab(c, s, tm);
+    msm_reduce<Fq>(c->sort_w, c->work1, 0, 2, &S->A, s, tm);  // ProofSums keeps A, B1 adjacent
     after_ab(s);
     msm_run<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, &S->L, s, tm);
   }
@@ -458,8 +466,16 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     const size_t reserve = (size_t)3 << 30;
     c->cfg_w = fit_config(lw ? lw : 1, o.window_bits, o.planes, 64 * 3 + 128, reserve);
     c->sort_w.init(lw, c->cfg_w);
-    c->ptsA.init((const G1Affine*)key->a_query + 1 + c->w_lo, lw, c->cfg_w, s);
-    c->ptsB1.init((const G1Affine*)key->b_g1_query + 1 + c->w_lo, lw, c->cfg_w, s);
+    // A and B1 are gathered by the same (scalar, digit, bucket) entries: interleaved point by point,
+    // one 128-byte line serves both (G16_NO_PAIR_AB=1: separate arrays, for A/B measurements)
+    static const bool no_pair = [] { const char* e = getenv("G16_NO_PAIR_AB"); return e && atoi(e) != 0; }();
+    if (no_pair) {
+      c->ptsA.init((const G1Affine*)key->a_query + 1 + c->w_lo, lw, c->cfg_w, s);
+      c->ptsB1.init((const G1Affine*)key->b_g1_query + 1 + c->w_lo, lw, c->cfg_w, s);
+    } else {
+      MsmPoints<Fq>::init_pair(c->ptsA, c->ptsB1, (const G1Affine*)key->a_query + 1 + c->w_lo,
+                               (const G1Affine*)key->b_g1_query + 1 + c->w_lo, lw, c->cfg_w, s);
+    }
     c->ptsB2.init((const G2Affine*)key->b_g2_query + 1 + c->w_lo, lw, c->cfg_w, s);
     {
       // L pairs l_query[j] with w[num_inputs + j], i.e. entry index i = p + j
@@ -490,7 +506,7 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
       const uint32_t nc_w = ceil_div(c->cfg_w.B, msm_red_chunk(c->cfg_w)) * c->cfg_w.D;
       const uint32_t nc_h = ceil_div(c->cfg_h.B, msm_red_chunk(c->cfg_h)) * c->cfg_h.D;
       const uint32_t slots_w = c->cfg_w.nb() + c->cfg_w.lanes, slots_h = c->cfg_h.nb() + c->cfg_h.lanes;
-      c->work1.init(slots_w, nc_w, c->cfg_w.D, /*batch=*/(c->cfg_w.nb() < (1u << 18) || getenv("G16_BATCH_REDUCE")) ? 3 : 1);
+      c->work1.init(slots_w, nc_w, c->cfg_w.D, /*batch=*/(c->cfg_w.nb() < (1u << 18) || getenv("G16_BATCH_REDUCE")) ? 3 : 2);
       c->workH.init(slots_h, nc_h, c->cfg_h.D, 1);
       c->work2.init(slots_w, nc_w, c->cfg_w.D);
     }
@@ -884,7 +900,8 @@ g16_status g16_stage_times(g16_ctx* c, float ms[G16_N_STAGES], uint32_t launches
 
 const char* g16_stage_name(int stage) {
   static const char* names[ST_COUNT] = {"witness_map",       "msm_sort",   "msm_accumulate_g1",
-                                        "msm_accumulate_g2", "msm_reduce", "finalize"};
+                                        "msm_accumulate_g2", "msm_reduce", "finalize",
+                                        "msm_accumulate_g1_pair"};
   return (stage >= 0 && stage < ST_COUNT) ? names[stage] : "?";
 }
 

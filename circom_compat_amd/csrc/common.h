@@ -76,10 +76,11 @@ struct DevBuf {
 enum Stage {
   ST_WITNESS_MAP = 0,  // sparse mat-vec + the six NTTs + pointwise (aux stream)
   ST_MSM_SORT,
-  ST_MSM_ACC_G1,  // k_bucket_accumulate<Fq>  -- the dominant kernel
+  ST_MSM_ACC_G1,  // k_bucket_accumulate<Fq>, one query per launch (L, H) -- the dominant kernel
   ST_MSM_ACC_G2,  // k_bucket_accumulate<Fq2>
   ST_MSM_REDUCE,
   ST_FINALIZE,
+  ST_MSM_ACC_G1_PAIR,  // k_bucket_accumulate<Fq, 2, true>: A and B1 in one launch (interleaved pair)
   ST_COUNT
 };
 

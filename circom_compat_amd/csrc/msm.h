@@ -99,10 +99,19 @@ template <class F>
 struct MsmPoints {
   MsmConfig cfg;
   uint32_t count = 0;
-  // [Pn][count], PACKED INTERNAL form (Lazy<F>): canonical x * 2^261 mod q in the 8 words of an Fq
+  // [Pn][count][stride], PACKED INTERNAL form (Lazy<F>): canonical x * 2^261 mod q in the 8 words of
+  // an Fq.  stride 1: this query alone.  stride 2: two queries over the same scalars interleaved
+  // point by point (A_i | B1_i = ONE 128-byte line per gather instead of two half-used ones);
+  // `off` selects this query's half, the second query is a view (`view`) of the first one's buffer.
   DevBuf<Affine<F>> pts;
+  const Affine<F>* view = nullptr;
+  uint32_t stride = 1, off = 0;
+  const Affine<F>* data() const { return view ? view : pts.p; }
   // uploads `count` affine points (packed Montgomery x|y, all-zero = infinity) and fills the planes
   void init(const Affine<F>* host_points, uint32_t count, const MsmConfig& cfg, hipStream_t stream);
+  // two queries of the same length interleaved in a's buffer (b becomes a view of it)
+  static void init_pair(MsmPoints& a, MsmPoints& b, const Affine<F>* host_a, const Affine<F>* host_b,
+                        uint32_t count, const MsmConfig& cfg, hipStream_t stream);
   // same, from points already in device memory (key generator)
   void init_from_device(const Affine<F>* dev_points, uint32_t count, const MsmConfig& cfg,
                         hipStream_t stream);
@@ -131,6 +140,12 @@ void msm_run(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min, MsmWor
 template <class F>
 void msm_accumulate(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min, MsmWork<F>& work,
                     int slot, hipStream_t stream, StageTimer* tm = nullptr);
+// a, b: the two halves of an interleaved pair (MsmPoints::init_pair).  ONE launch: the two waves of
+// a workgroup walk the same 64 segments, wave 0 adding a's points into `slot`, wave 1 b's points into
+// `slot + 1` -- the second wave finds the 128-byte line its neighbour just pulled in the cache.
+template <class F>
+void msm_accumulate_pair(const MsmSort& s, const MsmPoints<F>& a, const MsmPoints<F>& b,
+                         MsmWork<F>& work, int slot, hipStream_t stream, StageTimer* tm = nullptr);
 template <class F>
 void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, MsmAcc<F>* out_dev,
                 hipStream_t stream, StageTimer* tm = nullptr);

@@ -27,16 +27,18 @@ constexpr int SUM_THREADS = 128;
 // left in the packed internal form.  ctx-create only.
 template <class F>
 __global__ void __launch_bounds__(128) k_precompute_planes(Affine<F>* pts, uint32_t count, int Pn,
-                                                           int shift_bits) {
+                                                           int shift_bits, uint32_t stride,
+                                                           uint32_t off) {
   using LF = typename Lazy<F>::type;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  const Aff29<LF> p0 = affine_from_mont256<F>(pts[i]);
-  pts[i] = store_packed_affine<F>(p0);
+  pts += off;
+  const Aff29<LF> p0 = affine_from_mont256<F>(pts[(size_t)i * stride]);
+  pts[(size_t)i * stride] = store_packed_affine<F>(p0);
   XYZZ29<LF> q = XYZZ29<LF>::from_affine(p0);
   for (int j = 1; j < Pn; ++j) {
     for (int s = 0; s < shift_bits; ++s) q.dbl_in_place();
-    pts[(size_t)j * count + i] = store_packed_affine<F>(q.to_affine());
+    pts[((size_t)j * count + i) * stride] = store_packed_affine<F>(q.to_affine());
   }
 }
 
@@ -68,23 +70,24 @@ struct AccWay {
 // the arithmetic of the accumulation kernel
 __device__ uint32_t g_gather_mask = 0xffffffffu;
 
-template <class F>
+// pts already points at this query's half of an interleaved pair; PS = record stride in points
+template <class F, int PS>
 __device__ __forceinline__ void acc_fetch(const Affine<F>* __restrict__ pts, uint32_t npts,
                                           uint32_t idx_min, uint32_t en, Affine<F>& raw) {
   const uint32_t idx = en & MSM_IDX_MASK;
   if (idx >= idx_min) {
     const uint32_t plane = (en >> MSM_IDX_BITS) & 31u;
 #ifdef G16_DEBUG_GATHER
-    raw = pts[(size_t)(plane & g_gather_mask) * npts + ((idx - idx_min) & g_gather_mask)];
+    raw = pts[((size_t)(plane & g_gather_mask) * npts + ((idx - idx_min) & g_gather_mask)) * PS];
 #else
-    raw = pts[(size_t)plane * npts + (idx - idx_min)];
+    raw = pts[((size_t)plane * npts + (idx - idx_min)) * PS];
 #endif
   } else {
     raw = Affine<F>::infinity();  // entry below this query's range (public inputs of L)
   }
 }
 
-template <class F>
+template <class F, int PS>
 __device__ __forceinline__ void acc_way_init(AccWay<F>& w, uint32_t seg, uint32_t S, uint32_t M,
                                              const Affine<F>* __restrict__ pts, uint32_t npts,
                                              uint32_t idx_min, const uint32_t* __restrict__ entries,
@@ -104,7 +107,7 @@ __device__ __forceinline__ void acc_way_init(AccWay<F>& w, uint32_t seg, uint32_
     w.bnext = offset[w.g + 2 < nb ? w.g + 2 : nb];
     w.en_next = entries[w.pos];
     w.en_next2 = w.pos + 1 < w.end ? entries[w.pos + 1] : 0u;
-    acc_fetch<F>(pts, npts, idx_min, w.en_next, w.raw_next);
+    acc_fetch<F, PS>(pts, npts, idx_min, w.en_next, w.raw_next);
   }
 }
 
@@ -115,7 +118,7 @@ __device__ __forceinline__ void acc_way_init(AccWay<F>& w, uint32_t seg, uint32_
 // only waited for one iteration later (at the next point's unpack), when they have long completed.
 // With the boundary block first, every wave drained its fresh stores + a dependent offset[] load
 // whenever one of its lanes crossed a bucket boundary (~half of the iterations).
-template <class F>
+template <class F, int PS>
 __device__ __forceinline__ Aff29<typename Lazy<F>::type> acc_way_prepare(
     AccWay<F>& w, bool* step, const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min,
     const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset, uint32_t nb,
@@ -141,7 +144,7 @@ __device__ __forceinline__ Aff29<typename Lazy<F>::type> acc_way_prepare(
   if (*step) w.bnext = offset[w.g + 2 < nb ? w.g + 2 : nb];
   w.en_next = w.en_next2;
   if (*step && w.pos + 2 < w.end) w.en_next2 = entries[w.pos + 2];
-  if (*step && w.pos + 1 < w.end) acc_fetch<F>(pts, npts, idx_min, w.en_next, w.raw_next);
+  if (*step && w.pos + 1 < w.end) acc_fetch<F, PS>(pts, npts, idx_min, w.en_next, w.raw_next);
   return p;
 }
 
@@ -161,22 +164,35 @@ __device__ __forceinline__ void acc_way_commit(AccWay<F>& w, bool step,
 // runs as two rounds of resident workgroups; 1024 and 4096 workgroups measured slower).  Interleaving
 // two segments per lane in one basic block was measured and lost: ~450 VGPRs (1 wave per SIMD),
 // 21.4 vs 17.5 ms for the four G1 MSMs of a 2^22 proof; capped at 256 VGPRs it spills.
-template <class F>
+// PS = record stride in points (2: this query is one half of an interleaved pair,
+// MsmPoints::init_pair).  PAIR: both halves in one launch -- the two waves of a workgroup walk the SAME 64 segments, wave h over half h
+// of every 128-byte record into partial set h -- identical control flow, so the waves stay within an
+// iteration or two of each other and the later one finds the line in the cache.
+template <class F, int PS, bool PAIR>
 __global__ void __launch_bounds__(ACC_THREADS)
     k_bucket_accumulate(const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min,
                         const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset,
-                        uint32_t nb, uint32_t lanes, MsmAcc<F>* __restrict__ partial) {
+                        uint32_t nb, uint32_t lanes, MsmAcc<F>* __restrict__ partial,
+                        size_t slot_stride) {
   using LF = typename Lazy<F>::type;
   const uint32_t M = offset[nb];
   const uint32_t S = msm_seg_len(M, lanes);
-  const uint32_t nthreads = gridDim.x * blockDim.x;
-  for (uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x; t0 < lanes; t0 += nthreads) {
+  uint32_t nthreads = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (PAIR) {
+    const uint32_t half = threadIdx.x / (ACC_THREADS / 2);
+    pts += half;
+    partial += (size_t)half * slot_stride;
+    nthreads /= 2;
+    t0 = blockIdx.x * (ACC_THREADS / 2) + threadIdx.x % (ACC_THREADS / 2);
+  }
+  for (; t0 < lanes; t0 += nthreads) {
     AccWay<F> w;
-    acc_way_init<F>(w, t0, S, M, pts, npts, idx_min, entries, offset, nb);
+    acc_way_init<F, PS>(w, t0, S, M, pts, npts, idx_min, entries, offset, nb);
     if (!w.live) break;  // segments are handed out in order: nothing left for later threads either
     for (uint32_t it = 0; it < S; ++it) {
       bool step, special;
-      const Aff29<LF> p = acc_way_prepare<F>(w, &step, pts, npts, idx_min, entries, offset, nb, partial);
+      const Aff29<LF> p =
+          acc_way_prepare<F, PS>(w, &step, pts, npts, idx_min, entries, offset, nb, partial);
       const XYZZ29<LF> r = XYZZ29<LF>::madd_select(w.acc, p, &special);
       acc_way_commit<F>(w, step, r, special, p);
     }
@@ -366,7 +382,7 @@ void MsmPoints<F>::init_from_device(const Affine<F>* dev_points, uint32_t n, con
                          stream));
   // always: plane 0 is converted from the storage form to the packed internal form
   G16_LAUNCH((k_precompute_planes<F>), ceil_div(n, 128), 128, 0, stream, pts.p, n, cfg.Pn,
-             cfg.c * cfg.D);
+             cfg.c * cfg.D, 1u, 0u);
 }
 
 template <class F>
@@ -380,7 +396,28 @@ void MsmPoints<F>::init(const Affine<F>* host_points, uint32_t n, const MsmConfi
                          stream));
   // always: plane 0 is converted from the storage form to the packed internal form
   G16_LAUNCH((k_precompute_planes<F>), ceil_div(n, 128), 128, 0, stream, pts.p, n, cfg.Pn,
-             cfg.c * cfg.D);
+             cfg.c * cfg.D, 1u, 0u);
+}
+
+template <class F>
+void MsmPoints<F>::init_pair(MsmPoints<F>& a, MsmPoints<F>& b, const Affine<F>* host_a,
+                             const Affine<F>* host_b, uint32_t n, const MsmConfig& c,
+                             hipStream_t stream) {
+  a.cfg = b.cfg = c;
+  a.count = b.count = n;
+  a.stride = b.stride = 2;
+  a.off = 0;
+  b.off = 1;
+  a.pts.alloc((size_t)2 * c.Pn * (n ? n : 1));
+  a.view = nullptr;
+  b.view = a.pts.p;
+  if (!n) return;
+  const size_t rec = sizeof(Affine<F>);
+  G16_HIP(hipMemcpy2DAsync(a.pts.p, 2 * rec, host_a, rec, rec, n, hipMemcpyHostToDevice, stream));
+  G16_HIP(hipMemcpy2DAsync(a.pts.p + 1, 2 * rec, host_b, rec, rec, n, hipMemcpyHostToDevice, stream));
+  for (uint32_t h = 0; h < 2; ++h)
+    G16_LAUNCH((k_precompute_planes<F>), ceil_div(n, 128), 128, 0, stream, a.pts.p, n, c.Pn,
+               c.c * c.D, 2u, h);
 }
 
 template <class F>
@@ -415,9 +452,34 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
   (void)mask_set;
 #endif
   int id = tm ? tm->begin(acc_stage, stream) : -1;
-  G16_LAUNCH((k_bucket_accumulate<F>), grid, ACC_THREADS, 0, stream, (const Affine<F>*)P.pts.p,
-             P.count, idx_min, (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb,
-             cfg.lanes, work.partial.p + (size_t)slot * work.slots);
+  MsmAcc<F>* out = work.partial.p + (size_t)slot * work.slots;
+  if (P.stride == 2)
+    G16_LAUNCH((k_bucket_accumulate<F, 2, false>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
+               P.count, idx_min, (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb,
+               cfg.lanes, out, (size_t)0);
+  else
+    G16_LAUNCH((k_bucket_accumulate<F, 1, false>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
+               idx_min, (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb, cfg.lanes, out,
+               (size_t)0);
+  if (tm) tm->end(id, stream);
+}
+
+template <class F>
+void msm_accumulate_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoints<F>& B,
+                         MsmWork<F>& work, int slot, hipStream_t stream, StageTimer* tm) {
+  const MsmConfig& cfg = s.cfg;
+  const uint32_t nb = cfg.nb();
+  const int acc_stage = ST_MSM_ACC_G1_PAIR;
+  if (slot < 0 || slot + 2 > work.batch) throw std::runtime_error("msm_accumulate_pair: bad workspace slot");
+  if (A.stride != 2 || B.stride != 2 || A.data() != B.data() || A.off != 0 || B.off != 1 ||
+      A.count != B.count)
+    throw std::runtime_error("msm_accumulate_pair: the queries are not an interleaved pair");
+  // twice the workgroups of a single launch: each one covers 64 segments with both of its waves
+  const uint32_t grid = cfg.lanes / (ACC_THREADS / 2);
+  int id = tm ? tm->begin(acc_stage, stream) : -1;
+  G16_LAUNCH((k_bucket_accumulate<F, 2, true>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
+             (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb, cfg.lanes,
+             work.partial.p + (size_t)slot * work.slots, (size_t)work.slots);
   if (tm) tm->end(id, stream);
 }
 

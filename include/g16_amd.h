@@ -190,7 +190,7 @@ g16_status g16_prove_dist_phase3(g16_ctx* ctx, const void* recv_dev,
                                  uint8_t partial_out[G16_PARTIAL_BYTES]);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
-#define G16_N_STAGES 6
+#define G16_N_STAGES 7
 g16_status g16_set_profiling(g16_ctx* ctx, int enabled);
 /* HIP-event times accumulated since the last call; resets the accumulators.                       */
 g16_status g16_stage_times(g16_ctx* ctx, float ms[G16_N_STAGES], uint32_t launches[G16_N_STAGES]);

@@ -15,27 +15,41 @@ import sys
 from collections import defaultdict
 
 
-def main(root, log2, out):
-    acc = defaultdict(list)
-    for path in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
-        with open(path) as f:
-            for row in csv.DictReader(f):
-                if "k_bucket_accumulate<g16::Fp<" in row["Kernel_Name"]:
-                    acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-    m = {k: sum(v) / len(v) for k, v in acc.items()}
+def traffic(m):
     rd, r32, r64, r128 = (m.get(k, 0.0) for k in ("TCC_EA0_RDREQ", "TCC_EA0_RDREQ_32B", "TCC_EA0_RDREQ_64B", "TCC_EA0_RDREQ_128B"))
     other = max(rd - r32 - r64 - r128, 0.0)
     read_bytes = 32 * r32 + 64 * (r64 + other) + 128 * r128
     wr, w64 = m.get("TCC_EA0_WRREQ", 0.0), m.get("TCC_EA0_WRREQ_64B", 0.0)
     write_bytes = 64 * w64 + 32 * max(wr - w64, 0.0)
-    rec = {"kernel": "k_bucket_accumulate<Fq>", "log2_domain": int(log2), "launches_averaged": len(acc.get("TCC_EA0_RDREQ", [])),
+    return read_bytes, write_bytes
+
+
+def main(root, log2, out):
+    # single-query launches (L, H; every G1 launch when G16_NO_PAIR_AB=1) / the A|B1 pair launch
+    acc, pair = defaultdict(list), defaultdict(list)
+    for path in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                name = row["Kernel_Name"]
+                if "k_bucket_accumulate<g16::Fp<" not in name:
+                    continue
+                (pair if "2, true>" in name else acc)[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    m = {k: sum(v) / len(v) for k, v in acc.items()}
+    read_bytes, write_bytes = traffic(m)
+    rec = {"kernel": "k_bucket_accumulate<Fq, 1, false>", "log2_domain": int(log2), "launches_averaged": len(acc.get("TCC_EA0_RDREQ", [])),
            "read_bytes_per_launch": read_bytes, "write_bytes_per_launch": write_bytes,
            "traffic_bytes_per_launch": read_bytes + write_bytes,
            "fetch_size_kb": m.get("FETCH_SIZE"), "write_size_kb": m.get("WRITE_SIZE"),
            "counters": m, "source": "rocprofv3 --pmc, scripts/pmc_passes.sh (separate passes), " + root}
+    if pair:
+        mp = {k: sum(v) / len(v) for k, v in pair.items()}
+        pr, pw = traffic(mp)
+        rec.update({"pair_kernel": "k_bucket_accumulate<Fq, 2, true> (A and B1 over interleaved records, one launch)",
+                    "pair_read_bytes_per_launch": pr, "pair_write_bytes_per_launch": pw,
+                    "pair_traffic_bytes_per_launch": pr + pw, "pair_counters": mp})
     with open(out, "w") as f:
         json.dump(rec, f, indent=1)
-    print(json.dumps({k: rec[k] for k in ("read_bytes_per_launch", "write_bytes_per_launch", "fetch_size_kb", "write_size_kb")}))
+    print(json.dumps({k: rec[k] for k in rec if k.endswith("per_launch") or k.endswith("_kb")}))
 
 
 if __name__ == "__main__":
