@@ -94,6 +94,28 @@ def test_prove_test_zkey(lib, golden):
         assert not o.verify_proof(opk, [34], H.proof_from_bytes(proof.raw))
 
 
+def test_separate_a_b1_arrays_knob_gives_the_same_proof(lib, golden):
+    """G16_NO_PAIR_AB=1 (read once per process: A and B1 planes in separate arrays, two launches) is the
+    A/B partner of the interleaved A|B1 pair launch -- same bytes either way"""
+    import subprocess
+    import sys
+    import circom_compat_amd as cc
+    data = open(os.path.join(golden, "test.zkey"), "rb").read()
+    pk, mats = cc.read_zkey(data, lib=lib)
+    r, s = 12345678901234567890, 98765432109876543210
+    here = cc.Groth16.create_proof_with_reduction_and_matrices(pk, r, s, mats, 2, 1, [1, 33, 3, 11], lib=lib).raw
+    code = ("import sys, circom_compat_amd as cc\n"
+            "from circom_compat_amd import _binding\n"
+            f"lib = _binding.Library({lib.path!r})\n"
+            f"pk, mats = cc.read_zkey(open({os.path.join(golden, 'test.zkey')!r}, 'rb').read(), lib=lib)\n"
+            f"p = cc.Groth16.create_proof_with_reduction_and_matrices(pk, {r}, {s}, mats, 2, 1, [1, 33, 3, 11], lib=lib)\n"
+            "print(bytes(p.raw).hex())\n")
+    env = dict(os.environ, G16_NO_PAIR_AB="1", PYTHONPATH=os.pathsep.join(sys.path))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == bytes(here).hex()
+
+
 def test_witness_map_circuit2(lib, golden):
     """131 constraints with very uneven rows (65-term rows), n = 256; witness from the shipped .wtns"""
     import circom_compat_amd as cc
