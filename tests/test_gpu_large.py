@@ -239,10 +239,10 @@ def _vk_dict(pk):
                 ic=[o.g1_from_bytes(bytes(x)) for x in pk.vk.gamma_abc_g1])
 
 
-@pytest.mark.parametrize("k", [20, 22])
+@pytest.mark.parametrize("k", [20, 22, 24])
 def test_full_prove_headline_sizes_bytes_pairing_and_qap_identities(gpulib, k):
-    """BASELINE configs 2 / 3 (the bench circuit, 2^20 and the headline 2^22): ONE full prove through
-    the C ABI is
+    """BASELINE configs 2 / 3 / 4 (the bench circuit at 2^20, the headline 2^22, and configs[3]'s 2^24
+    circuit on ONE GPU: 84 GiB of point planes): ONE full prove through the C ABI is
       * byte-identical to the CPU restatement's proof of the same (pk, r, s, w)   [SURVEY 8(d)],
       * accepted by the pairing check, a wrong public input rejected            [zkey.rs:868-870],
     and the two O(n) scalar-side identities of SURVEY Appendix C.2 hold on the GPU's OWN h:
