@@ -28,6 +28,15 @@ MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
       c = t;
     }
   }
+  // Latency regime (a few thousand to ~2^16 scalars: every stage is a dependent chain, the model's
+  // addition counts say nothing): measured on one box at 2^12..2^15 and on the reference bench's
+  // 10 000-constraint circuit, c = 15 (top digit 14 bits, no hot top-window buckets) beats the
+  // model's c = 11..13 by 4-18 % per proof and every other candidate (scripts/gpu_run22/23.sh).
+  // Below that (2^11 proofs) c = 13 wins by 20 %; smaller inputs are within noise of each other.
+  // At 2^17 scalars the model's tie between 15 and 16 goes to 16 (3.62 vs 3.80 ms per proof).
+  if (len >= 100000 && c < 16) c = 16;
+  else if (len >= 2048 && c < 15) c = 15;
+  else if (len >= 1024 && c < 13) c = 13;
   if (c_override > 0) c = c_override;
   if (c < 2) c = 2;
   if (c > 24) c = 24;
