@@ -1,4 +1,5 @@
 # same-box A/B: two-level bucket reduction (no per-thread offset products; tail on the red stream) vs classic
+# NOTE: the kernels / knob this script A/B-ed were measured and dropped; the env variables are no longer read.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 one() { env "${@:2}" python bench.py --steps 10 --warmup 3 --cpu-log2 0 --log2 ${K:-22} 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); st=d['stages_ms_per_step']
