@@ -14,8 +14,10 @@ section 8(d) with m = 2^22 - 2 constraints, a real trapdoor key minted on the GP
 The SURVEY 8(d) step (host witness -> H2D -> ... -> 256 B D2H, witness in the ctx's page-locked
 staging buffer) is timed right after it and reported as `value_pcie_inclusive`.
 
-N > 1 (strong scaling of ONE proof): MSMs sharded by point range, witness map distributed
-(four-step NTTs, two all-to-all exchanges), 1 KiB partial records gathered and summed.
+N > 1 (strong scaling of ONE proof): MSMs sharded by bucket range (--shard buckets / auto: every GPU
+holds the whole key and the single-GPU window, keeps 1/N of the sorted bucket list; the only MSM
+traffic is the all-gather of h and a 1 KiB record per rank) or by point range (--shard points),
+witness map distributed (four-step NTTs, two all-to-all exchanges), records gathered and summed.
   mode "in-library"  (default when this process can see N devices): rank 0 drives all N GPUs through
                      ONE g16_ctx_create_multi ctx -- exchanges are peer copies over xGMI inside the
                      library, no Python between phases; the other ranks only keep the barriers;
@@ -206,7 +208,7 @@ def setup_prover(cc, torch, args, mode, rank, local_rank, n_gpus, world, one_gpu
         zkey_path = os.path.join(tempfile.gettempdir(), f"g16_bench_{os.getpid()}.zkey")
         cc.write_zkey(zkey_path, pk, mats)
         pk, mats = cc.read_zkey(zkey_path)
-    kw = dict(window_bits=args.window_bits, planes=args.planes)
+    kw = dict(window_bits=args.window_bits, planes=args.planes, shard=args.shard)
     if mode == "single":
         prover = cc.Prover(pk, mats, device=local_rank, **kw)
     elif mode == "inlib":
@@ -248,6 +250,8 @@ def main():
                     help="seconds of CPU work the baseline sample may take")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--planes", type=int, default=0)
+    ap.add_argument("--shard", choices=["auto", "points", "buckets"], default="auto",
+                    help="N > 1: MSMs cut by point range or by bucket range (auto: buckets when the key fits)")
     args = ap.parse_args()
 
     import torch
@@ -369,6 +373,21 @@ def main():
             recv = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         part_t = cc.device_tensor(prover.partial_buffer(), 1024, dev)
         gath_t = cc.device_tensor(prover.gather_buffer(), world * 1024, dev)
+        by_buckets = prover.info()["shard_mode"] == "buckets"
+        if dist_wm and by_buckets:
+            hb = prover.h_bytes()
+            h_all = cc.device_tensor(prover.h_gather_buffer(), world * hb, dev)
+            h_mine = h_all[rank * hb:(rank + 1) * hb]      # in place: sendbuff = recvbuff + rank * count
+
+        def gather_h():
+            with torch.cuda.stream(xs):
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(h_all, h_mine, group=grp)
+                else:
+                    xs.synchronize()
+                    hs = [torch.empty(hb, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(hs, h_mine.cpu())
+                    h_all.copy_(torch.cat(hs))
 
         def exchange():
             with torch.cuda.stream(xs):
@@ -398,7 +417,12 @@ def main():
             exchange()
             prover.dist_phase2(recv.data_ptr(), send.data_ptr())
             exchange()
-            prover.dist_phase3_dev(recv.data_ptr())
+            if by_buckets:
+                prover.dist_phase3h(recv.data_ptr())       # this rank's h scalars, in its slice of h_all
+                gather_h()
+                prover.dist_phase4_dev()
+            else:
+                prover.dist_phase3_dev(recv.data_ptr())
         else:
             raise SystemExit("mode 'ranks' runs the fully sharded prover (G16_BENCH_DIST_WM=1)")
         gather()
@@ -607,7 +631,9 @@ def main():
     if mode == "single":
         par = "single-gpu"
     else:
-        par = (f"msm-point-range-shard x{n_gpus} + four-step witness map (2 all-to-all), "
+        cut = ("msm-bucket-range-shard (whole key on every GPU, 1/N of the sorted bucket list per rank, h all-gather)"
+               if info.get("shard_mode") == "buckets" else "msm-point-range-shard")
+        par = (f"{cut} x{n_gpus} + four-step witness map (2 all-to-all), "
                + ("one g16_ctx_create_multi ctx in one process: peer copies over xGMI inside the library"
                   if mode == "inlib" else "one process per GPU: RCCL all_to_all / all_gather, event hand-offs"))
         if fallback_reason:

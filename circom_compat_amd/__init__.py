@@ -393,9 +393,11 @@ class Prover:
     def __init__(self, pk: Optional[ProvingKey], matrices: ConstraintMatrices, device=0, rank=0,
                  world=1, window_bits=0, planes=0, lib: Optional[B.Library] = None,
                  n_vars: Optional[int] = None, dist_wm=False, reduction: str = "circom",
-                 devices: Optional[Sequence[int]] = None):
+                 devices: Optional[Sequence[int]] = None, shard: str = "auto"):
         """devices=[d0, d1, ...]: ONE ctx sharded over several GPUs inside the library
-        (g16_ctx_create_multi); prove() / prove_dev() are then used exactly as on one device."""
+        (g16_ctx_create_multi); prove() / prove_dev() are then used exactly as on one device.
+        shard (world > 1 / devices): "points" = point-range MSM shards, "buckets" = every rank holds
+        the whole key and 1/world of the sorted bucket list, "auto" = buckets when the key fits."""
         self.lib = lib or B.load()
         self.matrices = matrices
         self.pk = pk
@@ -418,8 +420,9 @@ class Prover:
         opt = B.Options()
         opt.device, opt.rank, opt.world = device, rank, world
         opt.window_bits, opt.planes = window_bits, planes
-        opt.dist_wm = 1 if (dist_wm and world > 1) else 0
+        opt.dist_wm = 1 if dist_wm else 0
         opt.reduction = REDUCTIONS[reduction]
+        opt.shard = SHARD_MODES[shard]
         self.dist_wm = bool(opt.dist_wm)
         self.rank, self.world = rank, world
         a, b = matrices.a.to_c(), matrices.b.to_c()
@@ -528,6 +531,28 @@ class Prover:
                        self.ctx)
         return out.tobytes()
 
+    # -- bucket-sharded ranks: phase 3 leaves the rank's h scalars, phase 4 follows their all-gather
+    def h_bytes(self) -> int:
+        return int(self.lib.g16_dist_h_bytes(self.ctx))
+
+    def h_gather_buffer(self) -> int:
+        return int(self.lib.g16_h_gather_buffer(self.ctx) or 0)
+
+    def dist_phase3h(self, recv_ptr: int, h_send_ptr: Optional[int] = None):
+        self.lib.check(self.lib.g16_prove_dist_phase3h(self.ctx, C.c_void_p(recv_ptr),
+                                                       C.c_void_p(h_send_ptr) if h_send_ptr else None), self.ctx)
+
+    def dist_phase4(self, h_all_ptr: Optional[int] = None) -> bytes:
+        out = np.empty(B.G16_PARTIAL_BYTES, dtype=np.uint8)
+        self.lib.check(self.lib.g16_prove_dist_phase4(self.ctx, C.c_void_p(h_all_ptr) if h_all_ptr else None,
+                                                      _np_ptr(out)), self.ctx)
+        return out.tobytes()
+
+    def dist_phase4_dev(self, h_all_ptr: Optional[int] = None):
+        """phase 4 with the record left in partial_buffer() (needs set_exchange_stream)"""
+        self.lib.check(self.lib.g16_prove_dist_phase4(self.ctx, C.c_void_p(h_all_ptr) if h_all_ptr else None,
+                                                      None), self.ctx)
+
     def prove_finish(self, r, s, partials: bytes) -> Proof:
         rs = _as_fr([r, s], self.lib) if not isinstance(r, np.ndarray) else np.stack([r, s])
         world = len(partials) // B.G16_PARTIAL_BYTES
@@ -591,8 +616,10 @@ class Prover:
         out = (C.c_uint32 * 16)()
         self.lib.check(self.lib.g16_ctx_info(self.ctx, out), self.ctx)
         keys = ["c_w", "W_w", "planes_w", "D_w", "c_h", "W_h", "planes_h", "D_h", "domain_size",
-                "log_n", "shard_w", "shard_h", "devices"]
-        return dict(zip(keys, list(out)))
+                "log_n", "shard_w", "shard_h", "devices", "shard_mode", "peer_access"]
+        d = dict(zip(keys, list(out)))
+        d["shard_mode"] = {0: "none", 1: "points", 2: "buckets"}.get(d["shard_mode"], "?")
+        return d
 
 
 def _transpose_csr(m: Csr, n_cols: int, extra=None) -> Csr:
@@ -613,6 +640,7 @@ def _transpose_csr(m: Csr, n_cols: int, extra=None) -> Csr:
 
 
 REDUCTIONS = {"circom": 0, "libsnark": 1}
+SHARD_MODES = {"auto": B.SHARD_AUTO, "points": B.SHARD_POINTS, "buckets": B.SHARD_BUCKETS}
 
 
 def trapdoor_setup(a: Csr, b: Csr, c: Csr, n_vars: int, n_public: int, toxic: Sequence[int],

@@ -95,11 +95,13 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
   // A/B knobs (measurement only): G16_BATCH_REDUCE / G16_B2_RED_STREAM = 0 | 1 override the size rules
   static const int knob_batch = [] { const char* e = getenv("G16_BATCH_REDUCE"); return e ? atoi(e) : -1; }();
   static const int knob_b2 = [] { const char* e = getenv("G16_B2_RED_STREAM"); return e ? atoi(e) : -1; }();
-  const bool small = c->cfg_w.nb() < (1u << 18);
+  // buckets this ctx reduces per MSM: 1/world of the set under bucket-range sharding
+  const uint32_t nb_eff = c->cfg_w.nb() / (c->shard_buckets ? (uint32_t)c->world : 1u);
+  const bool small = nb_eff < (1u << 18);
   const uint32_t b2_limit = c->world > 1 ? (1u << 18) : (1u << 16);
-  const bool b2_off = c->overlap && (knob_b2 < 0 ? c->cfg_w.nb() < b2_limit : knob_b2 != 0);
+  const bool b2_off = c->overlap && (knob_b2 < 0 ? nb_eff < b2_limit : knob_b2 != 0);
   static const int knob_off = [] { const char* e = getenv("G16_REDUCE_OFF_MAIN"); return e ? atoi(e) : -1; }();
-  const bool mid = c->cfg_w.nb() >= (1u << 15) && small;
+  const bool mid = nb_eff >= (1u << 15) && small;
   if ((knob_off < 0 ? mid : knob_off != 0) && c->overlap && c->work1.batch >= 3) {
     // Mid-sized bucket sets (2^15..2^17: 2^18..2^20-constraint proofs, ranks of a sharded 2^22
     // one): every reduction is a latency-bound chain long enough to matter and short enough to
@@ -296,9 +298,31 @@ void rank_phase2_enqueue(g16_ctx* c, const int32_t* recv_dev, int32_t* send_dev)
 
 void rank_phase3_enqueue(g16_ctx* c, const int32_t* recv_dev) {
   G16_HIP(hipSetDevice(c->device));
+  if (c->shard_buckets) throw std::runtime_error("bucket-range sharding: phase 3 is followed by the all-gather of h and phase 4");
   hipStream_t s = c->stream, x = c->aux;
   c->wd.phase3(recv_dev, c->h_canon.p, x);
   c->sort_h.run(c->h_canon.p, c->h_hi - c->h_lo, /*mont=*/false, x);
+  G16_HIP(hipEventRecord(c->ev_h, x));
+  enqueue_h_msm(c);
+  G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));
+  sums_to_partial(c->sums_dev.p, c->part_dev(), s);
+  G16_HIP(hipEventRecord(c->ev_part, s));
+}
+
+void rank_phase3h_enqueue(g16_ctx* c, const int32_t* recv_dev, U256* h_out) {
+  G16_HIP(hipSetDevice(c->device));
+  const uint32_t per = c->n / (uint32_t)c->world;
+  c->wd.phase3(recv_dev, h_out ? h_out : c->h_canon.p + (size_t)c->rank * per, c->aux);
+  G16_HIP(hipEventRecord(c->ev_send, c->aux));
+}
+
+void rank_phase4_enqueue(g16_ctx* c, const U256* h_all) {
+  G16_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream, x = c->aux;
+  StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
+  int id = tm ? tm->begin(ST_MSM_SORT, x) : -1;
+  c->sort_h.run(h_all ? h_all : c->h_canon.p, c->n, /*mont=*/false, x);
+  if (tm) tm->end(id, x);
   G16_HIP(hipEventRecord(c->ev_h, x));
   enqueue_h_msm(c);
   G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));
@@ -336,38 +360,64 @@ const char* g16_last_error(const g16_ctx* ctx) {
   return copy.c_str();
 }
 
-g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
-                          uint32_t num_constraints, const g16_options* opt, g16_ctx** out) {
-  if (!key || !a || !b || !out) return fail(nullptr, G16_ERR_INVALID, "null argument");
+}  // extern "C"
+
+namespace g16 {
+
+bool bucket_shard_fits(int device, uint32_t n_vars, uint32_t domain, const g16_options* opt) {
+  if (hipSetDevice(device) != hipSuccess) return false;
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+  const size_t len_w = n_vars > 1 ? n_vars - 1 : 1;
+  const MsmConfig cw = msm_make_config(len_w, opt ? opt->window_bits : 0, opt ? opt->planes : 0);
+  const MsmConfig ch = msm_make_config(domain ? domain : 1, opt ? opt->window_bits : 0, opt ? opt->planes : 0);
+  // planes + both sorts (8 + 4 bytes per entry) + work buffers, against 70 % of what is free beyond 3 GiB
+  const size_t planes = (size_t)cw.Pn * len_w * (64 * 3 + 128) + (size_t)ch.Pn * domain * 64;
+  const size_t sorts = ((size_t)cw.W * len_w + (size_t)ch.W * domain) * 12;
+  const size_t work = ((size_t)cw.nb() + cw.lanes) * (144 * 3 + 288) + ((size_t)ch.nb() + ch.lanes) * 144;
+  const size_t reserve = (size_t)3 << 30;
+  return fr > reserve && planes + sorts + work < (size_t)((fr - reserve) * 0.7);
+}
+
+g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
+                           uint32_t num_constraints, const g16_options* opt, g16_ctx* share_from,
+                           g16_ctx** out, std::string* err) {
+  auto bad = [&](g16_status code, const std::string& msg) {
+    if (err) *err = msg;
+    return code;
+  };
+  if (!key || !a || !b || !out) return bad(G16_ERR_INVALID, "null argument");
   *out = nullptr;
   g16_options o{};
   if (opt) o = *opt;
   if (o.world <= 0) o.world = 1;
-  if (o.rank < 0 || o.rank >= o.world) return fail(nullptr, G16_ERR_INVALID, "bad rank/world");
+  if (o.rank < 0 || o.rank >= o.world) return bad(G16_ERR_INVALID, "bad rank/world");
+  if (o.shard < G16_SHARD_AUTO || o.shard > G16_SHARD_BUCKETS) return bad(G16_ERR_INVALID, "unknown shard mode");
   if ((uint64_t)key->n_vars < (uint64_t)key->n_public + 1)
-    return fail(nullptr, G16_ERR_INVALID, "n_vars < n_public+1");
+    return bad(G16_ERR_INVALID, "n_vars < n_public+1");
   // the kernels index w[col[j]] and col/coeff[row_ptr[i] .. row_ptr[i+1]) unchecked: validate once
   // here (the reference panics on an out-of-bounds wire index in evaluate_constraint)
   for (const g16_csr* mtx : {a, b}) {
     if (!mtx->row_ptr || (mtx->nnz && (!mtx->col || !mtx->coeff)))
-      return fail(nullptr, G16_ERR_INVALID, "matrix with null arrays");
+      return bad(G16_ERR_INVALID, "matrix with null arrays");
     if (mtx->row_ptr[0] != 0 || mtx->row_ptr[num_constraints] != mtx->nnz)
-      return fail(nullptr, G16_ERR_INVALID, "matrix row_ptr does not span [0, nnz]");
+      return bad(G16_ERR_INVALID, "matrix row_ptr does not span [0, nnz]");
     for (uint32_t i = 0; i < num_constraints; ++i)
       if (mtx->row_ptr[i] > mtx->row_ptr[i + 1])
-        return fail(nullptr, G16_ERR_INVALID, "matrix row_ptr is not monotone");
+        return bad(G16_ERR_INVALID, "matrix row_ptr is not monotone");
     for (uint64_t j = 0; j < mtx->nnz; ++j)
       if (mtx->col[j] >= key->n_vars)
-        return fail(nullptr, G16_ERR_INVALID, "matrix wire index >= n_vars");
+        return bad(G16_ERR_INVALID, "matrix wire index >= n_vars");
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(nullptr, G16_ERR_NO_DEVICE,
-                "no HIP device visible: this library has no CPU fallback");
-  if (o.device < 0 || o.device >= ndev) return fail(nullptr, G16_ERR_INVALID, "bad device ordinal");
+    return bad(G16_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+  if (o.device < 0 || o.device >= ndev) return bad(G16_ERR_INVALID, "bad device ordinal");
+  if (share_from && (share_from->device != o.device || !share_from->shard_buckets || !share_from->has_key))
+    return bad(G16_ERR_INVALID, "planes can only be shared with a bucket-sharded ctx on the same device");
 
   g16_ctx* c = new (std::nothrow) g16_ctx();
-  if (!c) return fail(nullptr, G16_ERR_INTERNAL, "host allocation failed");
+  if (!c) return bad(G16_ERR_INTERNAL, "host allocation failed");
   c->device = o.device;
   c->rank = o.rank;
   c->world = o.world;
@@ -418,7 +468,9 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     CsrHost B{b->row_ptr, b->col, (const Fr*)b->coeff, (size_t)b->nnz};
     if (o.reduction != G16_REDUCTION_CIRCOM && o.reduction != G16_REDUCTION_LIBSNARK)
       throw std::runtime_error("unknown reduction");
-    c->dist_wm = o.dist_wm != 0 && o.world > 1;
+    // (world = 1 with dist_wm > 0 is the degenerate one-rank case of the phase API: every exchange is
+    // a copy onto itself -- what a single-process run of the host framework's collectives exercises)
+    c->dist_wm = o.dist_wm > 0;
     if (c->dist_wm && o.reduction != G16_REDUCTION_CIRCOM)
       throw std::runtime_error("the distributed witness map implements CircomReduction only");
     if (c->dist_wm) {
@@ -432,18 +484,30 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
       throw std::runtime_error("key domain_size does not match num_constraints + num_inputs");
 
     const uint32_t len_w = c->N - 1;
-    shard(len_w, c->rank, c->world, &c->w_lo, &c->w_hi);
-    shard(c->n, c->rank, c->world, &c->h_lo, &c->h_hi);
-    if (c->dist_wm) {  // the distributed witness map leaves n / world scalars, local order
+    c->has_key = key->a_query != nullptr;
+    c->shard_buckets = (c->world > 1 || c->dist_wm) && c->has_key &&
+                       (o.shard == G16_SHARD_BUCKETS ||
+                        (o.shard == G16_SHARD_AUTO && (share_from || bucket_shard_fits(c->device, c->N, c->n, &o))));
+    c->share_from = c->shard_buckets ? share_from : nullptr;
+    if (c->shard_buckets) {  // every rank holds every point; the sorts keep 1/world of the entries
+      c->w_lo = 0;
+      c->w_hi = len_w;
       c->h_lo = 0;
-      c->h_hi = c->n / (uint32_t)c->world;
+      c->h_hi = c->n;
+    } else {
+      shard(len_w, c->rank, c->world, &c->w_lo, &c->w_hi);
+      shard(c->n, c->rank, c->world, &c->h_lo, &c->h_hi);
+      if (c->dist_wm) {  // the distributed witness map leaves n / world scalars, local order
+        c->h_lo = 0;
+        c->h_hi = c->n / (uint32_t)c->world;
+      }
     }
     const uint32_t lw = c->w_hi - c->w_lo, lh = c->h_hi - c->h_lo;
+    const uint32_t wr = c->shard_buckets ? (uint32_t)c->world : 1u;  // ranks sharing one bucket set
 
     c->w_dev.alloc(c->N);
     c->h_dev.alloc(c->n);
     c->h_canon.alloc(c->n);
-    c->has_key = key->a_query != nullptr;
     if (!c->has_key) {
       G16_HIP(hipStreamSynchronize(s));
       return G16_OK;
@@ -464,36 +528,62 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
 
     // MSM configurations: the four witness queries share one sort, hence one (c, W, planes)
     const size_t reserve = (size_t)3 << 30;
-    c->cfg_w = fit_config(lw ? lw : 1, o.window_bits, o.planes, 64 * 3 + 128, reserve);
+    g16_ctx* lender = c->share_from;
+    // point planes lent by another ctx of the same key on this device (ranks of a multi-device ctx
+    // that repeat a device ordinal): same configuration, views of its arrays
+    auto borrow = [](auto& mine, const auto& theirs) {
+      mine.cfg = theirs.cfg;
+      mine.count = theirs.count;
+      mine.stride = theirs.stride;
+      mine.off = theirs.off;
+      mine.view = theirs.data();
+    };
+    c->cfg_w = lender ? lender->cfg_w : fit_config(lw ? lw : 1, o.window_bits, o.planes, 64 * 3 + 128, reserve);
     c->sort_w.init(lw, c->cfg_w);
+    c->sort_w.set_shard(c->shard_buckets ? c->rank : 0, (int)wr);
     // A and B1 are gathered by the same (scalar, digit, bucket) entries: interleaved point by point,
     // one 128-byte line serves both (G16_NO_PAIR_AB=1: separate arrays, for A/B measurements)
     static const bool no_pair = [] { const char* e = getenv("G16_NO_PAIR_AB"); return e && atoi(e) != 0; }();
-    if (no_pair) {
-      c->ptsA.init((const G1Affine*)key->a_query + 1 + c->w_lo, lw, c->cfg_w, s);
-      c->ptsB1.init((const G1Affine*)key->b_g1_query + 1 + c->w_lo, lw, c->cfg_w, s);
+    if (lender) {
+      borrow(c->ptsA, lender->ptsA);
+      borrow(c->ptsB1, lender->ptsB1);
+      borrow(c->ptsB2, lender->ptsB2);
+      borrow(c->ptsL, lender->ptsL);
+      borrow(c->ptsH, lender->ptsH);
+      c->l_idx_min = lender->l_idx_min;
     } else {
-      MsmPoints<Fq>::init_pair(c->ptsA, c->ptsB1, (const G1Affine*)key->a_query + 1 + c->w_lo,
-                               (const G1Affine*)key->b_g1_query + 1 + c->w_lo, lw, c->cfg_w, s);
-    }
-    c->ptsB2.init((const G2Affine*)key->b_g2_query + 1 + c->w_lo, lw, c->cfg_w, s);
-    {
+      if (no_pair) {
+        c->ptsA.init((const G1Affine*)key->a_query + 1 + c->w_lo, lw, c->cfg_w, s);
+        c->ptsB1.init((const G1Affine*)key->b_g1_query + 1 + c->w_lo, lw, c->cfg_w, s);
+      } else {
+        MsmPoints<Fq>::init_pair(c->ptsA, c->ptsB1, (const G1Affine*)key->a_query + 1 + c->w_lo,
+                                 (const G1Affine*)key->b_g1_query + 1 + c->w_lo, lw, c->cfg_w, s);
+      }
+      c->ptsB2.init((const G2Affine*)key->b_g2_query + 1 + c->w_lo, lw, c->cfg_w, s);
       // L pairs l_query[j] with w[num_inputs + j], i.e. entry index i = p + j
       const uint32_t first = c->w_lo > c->p ? c->w_lo : c->p;  // first global entry with an L point
       const uint32_t cnt = c->w_hi > first ? c->w_hi - first : 0;
       c->l_idx_min = first - c->w_lo;
       c->ptsL.init((const G1Affine*)key->l_query + (first - c->p), cnt, c->cfg_w, s);
     }
-    c->cfg_h = fit_config(lh ? lh : 1, o.window_bits, o.planes, 64, reserve);
+    c->cfg_h = lender ? lender->cfg_h : fit_config(lh ? lh : 1, o.window_bits, o.planes, 64, reserve);
     c->sort_h.init(lh, c->cfg_h);
-    if (c->dist_wm) {
-      // this rank's h scalars are the evaluations e = global_index(t): gather the matching points
+    c->sort_h.set_shard(c->shard_buckets ? c->rank : 0, (int)wr);
+    if (lender) {
+      // planes borrowed above
+    } else if (c->dist_wm) {
+      // point-range shards: this rank's h scalars are the evaluations e = global_index(t) -- gather
+      // the matching points.  Bucket-range shards: all n scalars arrive rank after rank (the
+      // all-gather of the phase-3 outputs), so the whole H query is stored in that order.
       std::vector<G1Affine> mine(lh);
       const G1Affine* hq = (const G1Affine*)key->h_query;
+      const uint32_t per = c->n / (uint32_t)c->world;
       // byte copies: the caller's arrays carry no alignment (zero-copy views of zkey sections start
       // at arbitrary file offsets) and G1Affine is an over-aligned type
-      for (uint32_t t = 0; t < lh; ++t)
-        memcpy((void*)&mine[t], (const uint8_t*)hq + (size_t)c->wd.global_index(t) * sizeof(G1Affine), sizeof(G1Affine));
+      for (uint32_t t = 0; t < lh; ++t) {
+        const uint32_t e = c->shard_buckets ? c->wd.global_index_of((int)(t / per), t % per) : c->wd.global_index(t);
+        memcpy((void*)&mine[t], (const uint8_t*)hq + (size_t)e * sizeof(G1Affine), sizeof(G1Affine));
+      }
       c->ptsH.init(mine.data(), lh, c->cfg_h, s);
       G16_HIP(hipStreamSynchronize(s));  // `mine` is read by the async upload
     } else {
@@ -503,10 +593,10 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     // workspaces: G1 over the witness sort (3 slots when the reductions are batched), G1 over the h
     // sort, G2 over the witness sort
     {
-      const uint32_t nc_w = ceil_div(c->cfg_w.B, msm_red_chunk(c->cfg_w)) * c->cfg_w.D;
-      const uint32_t nc_h = ceil_div(c->cfg_h.B, msm_red_chunk(c->cfg_h)) * c->cfg_h.D;
+      const uint32_t nc_w = ceil_div(c->cfg_w.B, msm_red_chunk(c->cfg_w, 1, wr)) * c->cfg_w.D;
+      const uint32_t nc_h = ceil_div(c->cfg_h.B, msm_red_chunk(c->cfg_h, 1, wr)) * c->cfg_h.D;
       const uint32_t slots_w = c->cfg_w.nb() + c->cfg_w.lanes, slots_h = c->cfg_h.nb() + c->cfg_h.lanes;
-      c->work1.init(slots_w, nc_w, c->cfg_w.D, /*batch=*/(c->cfg_w.nb() < (1u << 18) || getenv("G16_BATCH_REDUCE")) ? 3 : 2);
+      c->work1.init(slots_w, nc_w, c->cfg_w.D, /*batch=*/(c->cfg_w.nb() / wr < (1u << 18) || getenv("G16_BATCH_REDUCE")) ? 3 : 2);
       c->workH.init(slots_h, nc_h, c->cfg_h.D, 1);
       c->work2.init(slots_w, nc_w, c->cfg_w.D);
     }
@@ -529,14 +619,23 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
     return G16_OK;
   });
   if (st != G16_OK) {
-    {
-      std::lock_guard<std::mutex> g(g_err_mu);
-      g_create_error = c->err;
-    }
+    if (err) *err = c->err;
     g16_ctx_destroy(c);
     return st;
   }
   *out = c;
+  return G16_OK;
+}
+
+}  // namespace g16
+
+extern "C" {
+
+g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
+                          uint32_t num_constraints, const g16_options* opt, g16_ctx** out) {
+  std::string err;
+  const g16_status st = ctx_create_impl(key, a, b, num_constraints, opt, nullptr, out, &err);
+  if (st != G16_OK) return fail(nullptr, st, err);
   return G16_OK;
 }
 
@@ -682,6 +781,7 @@ g16_status g16_prove_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], 
   }
   if (!c->has_key) return fail(c, G16_ERR_INVALID, "witness-map-only ctx has no resident key");
   if (c->world != 1) return fail(c, G16_ERR_INVALID, "g16_prove needs world == 1; use partial/finish");
+  if (c->dist_wm) return fail(c, G16_ERR_INVALID, "dist_wm ctx: use the g16_prove_dist_phase* calls");
   if (check_w(c, n_vars) != G16_OK) return G16_ERR_INVALID;
   return guarded(c, [&]() -> g16_status {
     hipStream_t s = c->stream;
@@ -858,6 +958,49 @@ g16_status g16_prove_dist_phase3(g16_ctx* c, const void* recv_dev,
   });
 }
 
+size_t g16_dist_h_bytes(const g16_ctx* c) {
+  return (c && c->dist_wm && c->shard_buckets) ? (size_t)(c->n / (uint32_t)c->world) * 32 : 0;
+}
+void* g16_h_gather_buffer(g16_ctx* c) {
+  return (c && !c->multi && c->has_key && c->shard_buckets) ? (void*)c->h_canon.p : nullptr;
+}
+
+g16_status g16_prove_dist_phase3h(g16_ctx* c, const void* recv_dev, void* h_send_dev) {
+  if (!c || !recv_dev) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx: use g16_prove");
+  if (!c->dist_wm || !c->has_key || !c->shard_buckets)
+    return fail(c, G16_ERR_INVALID, "not a bucket-sharded dist_wm proving ctx");
+  return guarded(c, [&]() -> g16_status {
+    handback(c, c->aux);
+    rank_phase3h_enqueue(c, (const int32_t*)recv_dev, (U256*)h_send_dev);
+    handoff(c, c->ev_send, c->aux);  // this rank's h scalars are complete
+    return G16_OK;
+  });
+}
+
+g16_status g16_prove_dist_phase4(g16_ctx* c, const void* h_all_dev,
+                                 uint8_t partial_out[G16_PARTIAL_BYTES]) {
+  if (!c) return fail(c, G16_ERR_INVALID, "null argument");
+  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx: use g16_prove");
+  if (!c->dist_wm || !c->has_key || !c->shard_buckets)
+    return fail(c, G16_ERR_INVALID, "not a bucket-sharded dist_wm proving ctx");
+  if (!partial_out && !c->have_xstream)
+    return fail(c, G16_ERR_INVALID, "partial_out == NULL needs an exchange stream (g16_partial_buffer hand-off)");
+  return guarded(c, [&]() -> g16_status {
+    hipStream_t s = c->stream;
+    handback(c, c->aux);  // the all-gather of h was enqueued on the exchange stream
+    rank_phase4_enqueue(c, (const U256*)h_all_dev);
+    if (partial_out) {
+      G16_HIP(hipMemcpyAsync(partial_out, c->part_dev(), G16_PARTIAL_BYTES, hipMemcpyDeviceToHost, s));
+      G16_HIP(hipStreamSynchronize(s));
+      collect_times(c);
+    } else {
+      G16_HIP(hipStreamWaitEvent(c->xstream, c->ev_part, 0));
+    }
+    return G16_OK;
+  });
+}
+
 g16_status g16_set_profiling(g16_ctx* c, int enabled) {
   if (!c) return G16_ERR_INVALID;
   for (int g = 0; g < multi_size(c); ++g) g16_set_profiling(multi_child(c, g), enabled);
@@ -910,6 +1053,7 @@ g16_status g16_ctx_info(const g16_ctx* c, uint32_t out[16]) {
   if (c->multi) {  // the shards are alike: report rank 0's configuration and the device count
     g16_status st = g16_ctx_info(multi_child(const_cast<g16_ctx*>(c), 0), out);
     out[12] = (uint32_t)multi_size(c);
+    out[14] = c->peer_state;
     return st;
   }
   memset(out, 0, 16 * sizeof(uint32_t));
@@ -920,6 +1064,7 @@ g16_status g16_ctx_info(const g16_ctx* c, uint32_t out[16]) {
   out[9] = (uint32_t)(c->dist_wm ? c->wd.k : c->wm.plan.base.k);
   out[10] = c->w_hi - c->w_lo;
   out[11] = c->h_hi - c->h_lo;
+  out[13] = c->world > 1 ? (c->shard_buckets ? G16_SHARD_BUCKETS : G16_SHARD_POINTS) : 0;
   return G16_OK;
 }
 

@@ -44,6 +44,14 @@ struct g16_ctx {
   // partial / phase-1 call for these (r, s)
   bool fixed_ready = false;
   uint64_t fixed_rs[8] = {0};
+  // Sharding of the MSMs over the ranks (options.shard):
+  //   point ranges  -- rank g holds the points [w_lo, w_hi) / [h_lo, h_hi) of every query and its own
+  //                    (smaller) window configuration;
+  //   bucket ranges -- every rank holds ALL points (w_lo = h_lo = 0) with the single-GPU window and
+  //                    keeps 1/world of the sorted (bucket, point) list (MsmSort::set_shard): the
+  //                    accumulation AND the bucket reduction shrink by world, nothing but the 1 KiB
+  //                    record leaves the device.
+  bool shard_buckets = false;
   // shard of the assignment-index space [0, N-1) (entry i <-> w[1+i]) and of [0, n) for H
   uint32_t w_lo = 0, w_hi = 0, h_lo = 0, h_hi = 0;
   uint32_t l_idx_min = 0;  // entries below this local index have no L point (public inputs)
@@ -71,6 +79,8 @@ struct g16_ctx {
   // parent of a single-process multi-device prover (g16_ctx_create_multi): holds no device state
   // of its own, only the per-device children and the exchange plumbing between them
   g16::Multi* multi = nullptr;
+  g16_ctx* share_from = nullptr;  // lender of the point planes (must outlive this ctx)
+  uint32_t peer_state = 0;        // multi-device parent: 1 = every peer pair has direct access, 2 = some copies are staged
 
   uint8_t* part_dev() { return out_dev.p + G16_PROOF_BYTES; }
   uint8_t* gathered_dev() { return out_dev.p + G16_PROOF_BYTES + G16_PARTIAL_BYTES; }
@@ -85,6 +95,18 @@ void rank_phase1_enqueue(g16_ctx* c, const uint64_t r[4], const uint64_t s[4], c
                          int32_t* send_dev);
 void rank_phase2_enqueue(g16_ctx* c, const int32_t* recv_dev, int32_t* send_dev);
 void rank_phase3_enqueue(g16_ctx* c, const int32_t* recv_dev);  // ... -> part_dev(), ev_part
+// bucket-range sharding: phase 3 ends with this rank's n / world h scalars in h_out (default: its
+// slice of h_canon), ev_send recorded; after the all-gather phase 4 sorts all n of them (h_all,
+// default h_canon) and runs the rank's share of the H MSM -> part_dev(), ev_part
+void rank_phase3h_enqueue(g16_ctx* c, const int32_t* recv_dev, U256* h_out);
+void rank_phase4_enqueue(g16_ctx* c, const U256* h_all);
+// internal create: `share_from` (same device, same key, bucket-range sharding) lends its point
+// planes; errors come back through *err (never through the process-global message)
+g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
+                           uint32_t num_constraints, const g16_options* opt, g16_ctx* share_from,
+                           g16_ctx** out, std::string* err);
+// true when the full-precomputation planes of the WHOLE key fit `device` (bucket-range sharding)
+bool bucket_shard_fits(int device, uint32_t n_vars, uint32_t domain, const g16_options* opt);
 void rank_partial_enqueue(g16_ctx* c, const uint64_t r[4], const uint64_t s[4], const Fr* w_dev);
 // gathered: world x G16_PARTIAL_BYTES already in c->gathered_dev() (ordered on the main stream)
 void rank_finish_enqueue(g16_ctx* c, const uint64_t r[4], const uint64_t s[4], int world);

@@ -44,22 +44,39 @@ struct MsmConfig {
   uint32_t nb() const { return (uint32_t)D * B; }
 };
 
+// level-1 partition of the counting sort = bucket >> msm_part_shift(nb): at most 1024 partitions
+inline int msm_part_shift(uint32_t nb) {
+  int bits = 0;
+  while (((uint64_t)1 << bits) < nb) ++bits;
+  return bits > 10 ? bits - 10 : 0;
+}
+
 // buckets per thread of k_bucket_reduce.  The kernel is a serial chain of ~3 EC additions per bucket
 // plus one lo * run product (~21 addition-equivalents) per thread, each addition ~9 us of one wave's
 // issue slots: one wave per SIMD (65536 threads) minimises chain x waves-per-SIMD.  Measured at
 // 2^22 (2^19 buckets): 8 per thread 5.0 ms of reductions per proof vs 6.35 ms at 4, 8.7 ms at 2.
-inline uint32_t msm_red_chunk(const MsmConfig& cfg, uint32_t nbatch = 1) {
+// `world` > 1 (bucket-range sharding, MsmSort::set_shard): this rank reduces ~1/world of the bucket
+// set, so the chunk shrinks with it (the threads outside the rank's range exit at once); a chunk
+// never exceeds a level-1 sort partition, whose boundaries the rank ranges are cut at.
+inline uint32_t msm_red_chunk(const MsmConfig& cfg, uint32_t nbatch = 1, uint32_t world = 1) {
   static const uint32_t lanes_target = [] {
     const char* e = getenv("G16_RED_LANES");  // tuning knob: threads the reduction aims for
     return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 65536u;
   }();
-  uint32_t ch = (uint32_t)(((uint64_t)nbatch * cfg.D * cfg.B) / lanes_target);
+  uint32_t ch = (uint32_t)(((uint64_t)nbatch * cfg.D * cfg.B) / ((uint64_t)lanes_target * (world ? world : 1)));
   if (ch < 1) ch = 1;
   static const uint32_t ch_max = [] {
     const char* e = getenv("G16_RED_MAX");
     return e && atoi(e) > 0 ? (uint32_t)atoi(e) : (uint32_t)MSM_RED_CHUNK;
   }();
   if (ch > ch_max) ch = ch_max;
+  if (world > 1) {  // largest power of two <= ch, <= 2^(partition shift)
+    uint32_t p2 = 1;
+    while (p2 * 2 <= ch) p2 *= 2;
+    ch = p2;
+    const uint32_t part = 1u << msm_part_shift(cfg.nb());
+    if (ch > part) ch = part;
+  }
   return ch;
 }
 
@@ -84,8 +101,18 @@ struct MsmSort {
   DevBuf<MsmPair> part;  // level-1 output: (entry, bucket) pairs ordered by partition
   DevBuf<uint32_t> count, offset, cursor, entries, multi_l, meta, scan_tmp;  // meta[1] = #hot buckets
   DevBuf<uint32_t> gcount1, part_off, cursor1;  // level-1 partition sizes / offsets / cursors
+  // Bucket-range sharding (set_shard, world > 1): every rank walks ALL `n` scalars but keeps only
+  // the (bucket, point) pairs of ITS contiguous run of level-1 partitions, chosen on the device from
+  // the partition histogram so that the ranks hold equal shares of the sorted entry list (every rank
+  // computes the same histogram from the same scalars, hence the same cut).  Bucket ids stay global:
+  // count / offset span all nb buckets (zero outside the rank's run), entries holds the rank's
+  // M_local = offset[nb] entries.  range = {p_lo, p_hi, entry_base, M_local, b_lo, b_hi}.
+  int rank = 0, world = 1;
+  DevBuf<uint32_t> range;
+  const uint32_t* range_dev() const { return world > 1 ? range.p : nullptr; }
 
   void init(uint32_t capacity, const MsmConfig& cfg);
+  void set_shard(int rank, int world);
   // scalars: `n` field elements (Montgomery Fr when mont, else canonical U256) in device memory
   void run(const void* scalars, uint32_t n, bool mont, hipStream_t stream);
   size_t device_bytes() const;

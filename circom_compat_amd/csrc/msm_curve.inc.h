@@ -256,13 +256,22 @@ __global__ void __launch_bounds__(COMB_THREADS)
 }
 
 // contribution of buckets [lo, lo+L) of one set: sum (b+1) S_b = sum (b-lo+1) S_b + lo * sum S_b
+// range != nullptr (bucket-range sharding, MsmSort::range): only the chunks of this rank's run of
+// global bucket ids [range[4], range[5]) are reduced -- thread t takes chunk range[4] / red_chunk + t
+// (the run starts on a chunk boundary: msm_red_chunk) and the threads past the run exit at once;
+// contrib keeps its global layout, k_set_sum reads the same run.
 template <class F>
 __global__ void __launch_bounds__(64)
     k_bucket_reduce(const MsmAcc<F>* __restrict__ partial, const uint32_t* __restrict__ offset,
                     uint32_t nb, uint32_t lanes, uint32_t B, uint32_t red_chunk,
                     uint32_t chunks_per_set, uint32_t nchunks, MsmAcc<F>* contrib,
-                    size_t slot_stride) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+                    size_t slot_stride, const uint32_t* __restrict__ range) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (range) {
+    const uint32_t q_lo = range[4] / red_chunk, q_hi = (range[5] + red_chunk - 1) / red_chunk;
+    if (q >= q_hi - q_lo || q_hi <= q_lo) return;
+    q += q_lo;
+  }
   if (q >= nchunks) return;
   partial += (size_t)blockIdx.y * slot_stride;
   contrib += (size_t)blockIdx.y * nchunks;
@@ -338,18 +347,28 @@ __global__ void __launch_bounds__(64)
 }
 
 // tree-sum: block (set, blk) of a (sets x nblk) grid sums its slice of the `per_set` inputs of the set
+// range != nullptr: only the chunk contributions of the rank's bucket run exist (k_bucket_reduce)
 template <class F>
 __global__ void __launch_bounds__(SUM_THREADS)
     k_set_sum(const MsmAcc<F>* __restrict__ in, uint32_t per_set, uint32_t nblk, MsmAcc<F>* out,
-              size_t in_stride, size_t out_stride) {
+              size_t in_stride, size_t out_stride, const uint32_t* __restrict__ range,
+              uint32_t red_chunk) {
   G16_DYN_SMEM(smem_raw);
   MsmAcc<F>* sh = reinterpret_cast<MsmAcc<F>*>(smem_raw);
   in += (size_t)blockIdx.y * in_stride;
   out += (size_t)blockIdx.y * out_stride;
   const uint32_t set = blockIdx.x / nblk, blk = blockIdx.x % nblk;
   const MsmAcc<F>* c = in + (size_t)set * per_set;
+  uint32_t k_lo = 0, k_hi = per_set;
+  if (range) {
+    const uint64_t q_lo = range[4] / red_chunk, q_hi = (range[5] + red_chunk - 1) / red_chunk;
+    const uint64_t s_lo = (uint64_t)set * per_set, s_hi = s_lo + per_set;
+    const uint64_t a = q_lo > s_lo ? q_lo : s_lo, b = q_hi < s_hi ? q_hi : s_hi;
+    k_lo = b > a ? (uint32_t)(a - s_lo) : 0u;
+    k_hi = b > a ? (uint32_t)(b - s_lo) : 0u;
+  }
   MsmAcc<F> acc = MsmAcc<F>::infinity();
-  for (uint32_t k = blk * SUM_THREADS + threadIdx.x; k < per_set; k += nblk * SUM_THREADS)
+  for (uint32_t k = k_lo + blk * SUM_THREADS + threadIdx.x; k < k_hi; k += nblk * SUM_THREADS)
     acc.add(c[k]);
   MsmAcc<F> tot = block_sum<F, SUM_THREADS>(acc, sh);
   if (threadIdx.x == 0) out[blockIdx.x] = tot;
@@ -500,22 +519,24 @@ void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, 
              (const uint32_t*)s.offset.p, nb, cfg.lanes, partial, (size_t)work.slots);
   // buckets per thread: the running sums are a dependent chain of EC additions (~10 us each on
   // one lane): see msm_red_chunk for the thread count this aims at
-  const uint32_t red_chunk = msm_red_chunk(cfg, (uint32_t)nbatch);
+  const uint32_t* rng = s.range_dev();  // bucket-range sharding: this rank's run of the bucket set
+  const uint32_t red_chunk = msm_red_chunk(cfg, (uint32_t)nbatch, (uint32_t)s.world);
   const uint32_t cps = ceil_div(cfg.B, red_chunk);
   const uint32_t nchunks = cps * (uint32_t)cfg.D;
   if (nchunks > work.ncontrib) throw std::runtime_error("msm_reduce: contribution buffer too small");
   G16_LAUNCH((k_bucket_reduce<F>), dim3(ceil_div(nchunks, 64), nbatch), 64, 0, stream,
              (const MsmAcc<F>*)partial, (const uint32_t*)s.offset.p, nb, cfg.lanes, cfg.B, red_chunk,
-             cps, nchunks, work.contrib.p, (size_t)work.slots);
+             cps, nchunks, work.contrib.p, (size_t)work.slots, rng);
   // two-level tree: cps contributions -> nblk block sums -> 1 per set
-  uint32_t nblk = ceil_div(cps, SUM_THREADS * 2);
+  uint32_t nblk = ceil_div(cps / (uint32_t)s.world, SUM_THREADS * 2);
   if (nblk > 256) nblk = 256;
+  if (nblk < 1) nblk = 1;
   G16_LAUNCH((k_set_sum<F>), dim3((uint32_t)cfg.D * nblk, nbatch), SUM_THREADS,
              SUM_THREADS * sizeof(MsmAcc<F>), stream, (const MsmAcc<F>*)work.contrib.p, cps, nblk,
-             work.bsum.p, (size_t)nchunks, (size_t)256 * work.sets);
+             work.bsum.p, (size_t)nchunks, (size_t)256 * work.sets, rng, red_chunk);
   G16_LAUNCH((k_set_sum<F>), dim3((uint32_t)cfg.D, nbatch), SUM_THREADS,
              SUM_THREADS * sizeof(MsmAcc<F>), stream, (const MsmAcc<F>*)work.bsum.p, nblk, 1u,
-             work.wsum.p, (size_t)256 * work.sets, (size_t)work.sets);
+             work.wsum.p, (size_t)256 * work.sets, (size_t)work.sets, (const uint32_t*)nullptr, 1u);
   G16_LAUNCH((k_horner<F>), nbatch, 64, 0, stream, (const MsmAcc<F>*)work.wsum.p, work.sets, cfg.D,
              cfg.c, out_dev);
   if (tm) tm->end(id, stream);

@@ -173,13 +173,56 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_count(const void* scalars, 
     if (h[b]) atomicAdd(&gcount1[b], h[b]);
 }
 
+// Cuts the partition-ordered list into `world` contiguous runs of whole partitions with (nearly)
+// equal entry counts and leaves rank's run in range[] (MsmSort::range).  One thread: <= 1024
+// partitions.  Every rank runs this on the same histogram, so the cuts agree without a message.
+// A partition joins the current run when that brings the run closer to its target (the remaining
+// entries over the remaining ranks, so rounding never accumulates); one hot partition larger than a
+// fair share gets a rank to itself.
+__global__ void k_pick_range(const uint32_t* part_off, uint32_t bins1, int sh, uint32_t nb, int rank,
+                             int world, uint32_t* range) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint32_t M = part_off[bins1];
+  uint32_t p = 0, lo = 0, hi = 0;
+  for (int g = 0; g <= rank; ++g) {
+    lo = p;
+    if (g == world - 1) {
+      p = bins1;
+    } else {
+      const uint64_t rem = (uint64_t)M - part_off[p];
+      const uint64_t tgt = rem / (uint64_t)(world - g);
+      uint64_t acc = 0;
+      while (p < bins1) {
+        const uint64_t cnt = (uint64_t)part_off[p + 1] - part_off[p];
+        if (acc + cnt / 2 > tgt && !(acc == 0 && cnt != 0 && tgt != 0)) break;
+        acc += cnt;
+        ++p;
+      }
+    }
+    hi = p;
+  }
+  range[0] = lo;
+  range[1] = hi;
+  range[2] = part_off[lo];
+  range[3] = part_off[hi] - part_off[lo];
+  const uint64_t b_lo = (uint64_t)lo << sh, b_hi = (uint64_t)hi << sh;
+  range[4] = (uint32_t)(b_lo < nb ? b_lo : nb);
+  range[5] = (uint32_t)(b_hi < nb ? b_hi : nb);
+}
+
+// range != nullptr (bucket-range sharding): only the pairs of partitions [range[0], range[1]) are
+// kept, written at their position minus range[2]
 template <bool MONT>
 __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars, uint32_t n,
                                                              SortGeom G, uint32_t* cursor1,
-                                                             MsmPair* part) {
+                                                             MsmPair* part,
+                                                             const uint32_t* __restrict__ range) {
   __shared__ uint32_t h[P1_MAX_BINS];
   const int tid = threadIdx.x;
   const uint32_t ntiles = (n + P1_TILE - 1) / P1_TILE;
+  const uint32_t p_lo = range ? range[0] : 0u, p_hi = range ? range[1] : G.bins1;
+  const uint32_t base = range ? range[2] : 0u;
+  if (p_lo >= p_hi) return;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     for (uint32_t b = tid; b < G.bins1; b += P1_THREADS) h[b] = 0;
     // the tile's scalars are read (and brought to canonical form) once and stay in registers for
@@ -197,13 +240,15 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
 #pragma unroll
     for (int k = 0; k < P1_PER_THREAD; ++k)
       if (live[k])
-        for_each_digit(sc[k], idx[k], G.c, G.W, G.D, G.B,
-                       [&](uint32_t g, uint32_t) { atomicAdd(&h[g >> G.sh], 1u); });
+        for_each_digit(sc[k], idx[k], G.c, G.W, G.D, G.B, [&](uint32_t g, uint32_t) {
+          const uint32_t pb = g >> G.sh;
+          if (pb >= p_lo && pb < p_hi) atomicAdd(&h[pb], 1u);
+        });
     __syncthreads();
     // reserve this tile's run in every partition; h[] becomes the running write cursor
-    for (uint32_t b = tid; b < G.bins1; b += P1_THREADS) {
+    for (uint32_t b = p_lo + tid; b < p_hi; b += P1_THREADS) {
       const uint32_t cnt = h[b];
-      h[b] = cnt ? atomicAdd(&cursor1[b], cnt) : 0u;
+      h[b] = cnt ? atomicAdd(&cursor1[b], cnt) - base : 0u;
     }
     __syncthreads();
     // four scalars advance window by window together: their four LDS ranks are issued back to
@@ -221,7 +266,11 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           v[u] = live[k0 + u] && wk[u].next(w, idx[k0 + u], G.c, G.D, G.B, &g[u], &e[u]);
-          if (v[u]) pos[u] = atomicAdd(&h[g[u] >> G.sh], 1u);
+          if (v[u]) {
+            const uint32_t pb = g[u] >> G.sh;
+            v[u] = pb >= p_lo && pb < p_hi;
+            if (v[u]) pos[u] = atomicAdd(&h[pb], 1u);
+          }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -423,6 +472,13 @@ __global__ void __launch_bounds__(256) k_find_large(const uint32_t* offset, uint
 }  // namespace
 
 
+void MsmSort::set_shard(int rank_, int world_) {
+  if (world_ < 1 || rank_ < 0 || rank_ >= world_) throw std::runtime_error("MsmSort::set_shard: bad rank/world");
+  rank = rank_;
+  world = world_;
+  if (world > 1) range.alloc(8);
+}
+
 void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   cfg = c;
   cap = capacity;
@@ -458,9 +514,7 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
   G.W = cfg.W;
   G.D = cfg.D;
   G.B = cfg.B;
-  int bits = 0;
-  while (((uint64_t)1 << bits) < nb) ++bits;
-  G.sh = bits > 10 ? bits - 10 : 0;
+  G.sh = msm_part_shift(nb);
   G.bins1 = ((nb - 1) >> G.sh) + 1;
   G16_HIP(hipMemsetAsync(count.p, 0, ((size_t)nb + 1) * 4, s));
   G16_HIP(hipMemsetAsync(gcount1.p, 0, (P1_MAX_BINS + 1) * 4, s));
@@ -480,10 +534,16 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
   if (mont) G16_LAUNCH((k_part_count<true>), grid1, P1_THREADS, 0, s, scalars, n, G, gcount1.p);
   else G16_LAUNCH((k_part_count<false>), grid1, P1_THREADS, 0, s, scalars, n, G, gcount1.p);
   scan_exclusive(gcount1.p, G.bins1, 0, part_off.p, cursor1.p, scan_tmp.p, s);
-  if (mont) G16_LAUNCH((k_part_scatter<true>), grid1, P1_THREADS, 0, s, scalars, n, G, cursor1.p, part.p);
-  else G16_LAUNCH((k_part_scatter<false>), grid1, P1_THREADS, 0, s, scalars, n, G, cursor1.p, part.p);
-  // level 2: bucket sizes, offsets, final placement
-  const uint32_t* total = part_off.p + G.bins1;
+  const uint32_t* rng = range_dev();
+  if (rng)
+    G16_LAUNCH(k_pick_range, 1, 64, 0, s, (const uint32_t*)part_off.p, G.bins1, G.sh, nb, rank, world,
+               range.p);
+  if (mont)
+    G16_LAUNCH((k_part_scatter<true>), grid1, P1_THREADS, 0, s, scalars, n, G, cursor1.p, part.p, rng);
+  else
+    G16_LAUNCH((k_part_scatter<false>), grid1, P1_THREADS, 0, s, scalars, n, G, cursor1.p, part.p, rng);
+  // level 2: bucket sizes, offsets, final placement (over this rank's pairs only when sharded)
+  const uint32_t* total = rng ? rng + 3 : part_off.p + G.bins1;
   G16_LAUNCH(k_bucket_count, grid2, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, count.p);
   scan_exclusive(count.p, nb, 0, offset.p, cursor.p, scan_tmp.p, s);
   uint32_t grid3 = ceil_div((uint64_t)n * cfg.W, P2S_CHUNK);

@@ -170,11 +170,14 @@ struct Multi {
   int G = 0;
   std::vector<g16_ctx*> ch;
   bool dist = false;    // fully sharded: the witness map is distributed too (power-of-two G)
+  bool buckets = false;  // MSMs sharded by bucket range (every device holds the whole key), else by point range
   size_t chunk_ints = 0;  // int32 per (source, destination) pair and exchange
   struct Dev {
     DevBuf<int32_t> send[2], recv[2];
     std::vector<hipStream_t> cs;            // one copy stream per destination
-    std::vector<hipEvent_t> arrived[2];     // [exchange][dst]: my chunk has landed in dst's recv buffer
+    // [exchange][dst]: my chunk has landed in dst's buffer.  Exchanges 0, 1: the all-to-all
+    // transposes of the witness map; 2: the all-gather of h (bucket-range sharding)
+    std::vector<hipEvent_t> arrived[3];
   };
   std::vector<std::unique_ptr<Dev>> dv;  // DevBuf is not movable
   bool witness_resident = false;  // g16_witness_upload: every child's w_dev holds the current witness
@@ -183,14 +186,33 @@ struct Multi {
 
 namespace {
 
-void enable_peers(const std::vector<g16_ctx*>& ch) {
+// Direct peer access for every ordered pair of distinct devices.  Returns 1 when all of them have
+// it, 2 when at least one does not: hipMemcpyPeerAsync still works then, but the runtime stages
+// the copy (through host memory), which turns every exchange of a proof into two PCIe crossings.
+// That is reported (g16_ctx_info out[14]), never hidden; G16_REQUIRE_PEER_ACCESS=1 makes it an error.
+uint32_t enable_peers(const std::vector<g16_ctx*>& ch, std::string* why) {
+  uint32_t state = 1;
   for (auto* a : ch)
     for (auto* b : ch) {
       if (a->device == b->device) continue;
       G16_HIP(hipSetDevice(a->device));
-      (void)hipDeviceEnablePeerAccess(b->device, 0);  // already enabled / unsupported: the copies
-      (void)hipGetLastError();                        // still work (staged through the host)
+      int can = 0;
+      hipError_t e = hipDeviceCanAccessPeer(&can, a->device, b->device);
+      if (e == hipSuccess && can) {
+        e = hipDeviceEnablePeerAccess(b->device, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
+      } else if (e == hipSuccess) {
+        e = hipErrorPeerAccessUnsupported;
+      }
+      (void)hipGetLastError();
+      if (e != hipSuccess) {
+        state = 2;
+        if (why && why->empty())
+          *why = "no direct peer access from device " + std::to_string(a->device) + " to device " +
+                 std::to_string(b->device) + " (" + hipGetErrorString(e) + ")";
+      }
     }
+  return state;
 }
 
 // exchange x of rank g: its G chunks go to the G recv buffers (own chunk included), each on its
@@ -206,6 +228,23 @@ void push_chunks(Multi& M, int g, int x) {
     G16_HIP(hipMemcpyPeerAsync(M.dv[d]->recv[x].p + (size_t)g * M.chunk_ints, M.ch[d]->device,
                                me.send[x].p + (size_t)d * M.chunk_ints, c->device, bytes, st));
     G16_HIP(hipEventRecord(me.arrived[x][d], st));
+  }
+}
+
+// all-gather of h (bucket-range sharding): rank g's n / G scalars sit in its own h_canon slice
+// (phase 3 wrote them there) and are pushed into the same slice of every peer's h_canon
+void push_h(Multi& M, int g) {
+  g16_ctx* c = M.ch[g];
+  Multi::Dev& me = *M.dv[g];
+  const size_t per = c->n / (size_t)M.G;
+  for (int k = 0; k < M.G; ++k) {
+    const int d = (g + k) % M.G;
+    hipStream_t st = me.cs[d];
+    G16_HIP(hipStreamWaitEvent(st, c->ev_send, 0));
+    if (d != g)
+      G16_HIP(hipMemcpyPeerAsync(M.ch[d]->h_canon.p + (size_t)g * per, M.ch[d]->device,
+                                 c->h_canon.p + (size_t)g * per, c->device, per * sizeof(U256), st));
+    G16_HIP(hipEventRecord(me.arrived[2][d], st));
   }
 }
 
@@ -257,7 +296,7 @@ void multi_destroy(Multi* M) {
     for (auto& b : M->dv[g]->send) b.release();
     for (auto& b : M->dv[g]->recv) b.release();
   }
-  for (auto* c : M->ch) g16_ctx_destroy(c);
+  for (auto it = M->ch.rbegin(); it != M->ch.rend(); ++it) g16_ctx_destroy(*it);  // borrowers before their lenders
   delete M;
 }
 
@@ -276,23 +315,37 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
   const bool libsnark = opt && opt->reduction == G16_REDUCTION_LIBSNARK;
   M->dist = is_pow2(n_dev) && n_dev > 1 && !libsnark && (1u << (k / 2)) >= (uint32_t)n_dev &&
             !(opt && opt->dist_wm < 0);
+  // bucket-range sharding when asked for, or (AUTO) when the full planes of the whole key fit one
+  // device; point ranges otherwise
+  const int want = opt ? opt->shard : G16_SHARD_AUTO;
+  M->buckets = want == G16_SHARD_BUCKETS ||
+               (want == G16_SHARD_AUTO && bucket_shard_fits(device_ids[0], key->n_vars, key->domain_size, opt));
   M->pool.start(n_dev);
-  std::vector<std::string> errs(n_dev);
-  std::vector<std::function<void(int)>> st;
-  st.push_back([&](int g) {
+  // ranks that repeat a device ordinal (functional runs of an N-rank prover on fewer GPUs) borrow
+  // the point planes of the first rank on that device under bucket-range sharding, where every
+  // rank's planes are the whole key: created in a second stage, after their lenders
+  std::vector<int> lender(n_dev, -1);
+  for (int g = 0; g < n_dev; ++g)
+    for (int f = 0; f < g && M->buckets; ++f)
+      if (device_ids[f] == device_ids[g]) {
+        lender[g] = f;
+        break;
+      }
+  auto make_child = [&](int g) {
     g16_options o{};
     if (opt) o = *opt;
     o.device = device_ids[g];
     o.rank = g;
     o.world = n_dev;
     o.dist_wm = M->dist ? 1 : 0;
+    o.shard = M->buckets ? G16_SHARD_BUCKETS : G16_SHARD_POINTS;
     g16_ctx* c = nullptr;
-    const g16_status s = g16_ctx_create(key, a, b, num_constraints, &o, &c);
-    if (s != G16_OK) {
-      errs[g] = g16_last_error(nullptr);
-      throw std::runtime_error("device " + std::to_string(device_ids[g]) + ": " + errs[g] +
+    std::string cerr;
+    const g16_status s = ctx_create_impl(key, a, b, num_constraints, &o, lender[g] >= 0 ? M->ch[lender[g]] : nullptr,
+                                         &c, &cerr);
+    if (s != G16_OK)
+      throw std::runtime_error("device " + std::to_string(device_ids[g]) + ": " + cerr +
                                (s == G16_ERR_DOMAIN_TOO_LARGE ? " PolynomialDegreeTooLarge" : ""));
-    }
     M->ch[g] = c;
     Multi::Dev& d = *M->dv[g];
     G16_HIP(hipSetDevice(c->device));
@@ -306,7 +359,7 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
     G16_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     d.cs.assign(n_dev, nullptr);
     for (auto& s2 : d.cs) G16_HIP(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio_hi));
-    for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < 3; ++x) {
       d.arrived[x].assign(n_dev, nullptr);
       for (auto& e : d.arrived[x]) G16_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
@@ -317,12 +370,25 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
         d.recv[x].alloc(ints);
       }
     }
+  };
+  std::vector<std::function<void(int)>> st;
+  st.push_back([&](int g) {
+    if (lender[g] < 0) make_child(g);
+  });
+  st.push_back([&](int g) {
+    if (lender[g] >= 0) make_child(g);
   });
   int code = M->pool.run(st);
+  uint32_t peer_state = 0;
   if (code == G16_OK) {
     try {
       if (M->dist) M->chunk_ints = M->ch[0]->wd.exchange_ints() / (size_t)n_dev;
-      enable_peers(M->ch);
+      std::string why;
+      peer_state = enable_peers(M->ch, &why);
+      const char* req = getenv("G16_REQUIRE_PEER_ACCESS");
+      if (peer_state != 1 && req && atoi(req) != 0) throw std::runtime_error("G16_REQUIRE_PEER_ACCESS: " + why);
+      if (peer_state != 1)
+        fprintf(stderr, "libg16_amd: %s -- the exchanges of every proof will be staged by the runtime\n", why.c_str());
     } catch (const std::exception& e) {
       code = G16_ERR_HIP;
       M->pool.first_error = e.what();
@@ -343,6 +409,7 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
   parent->m = M->ch[0]->m;
   parent->num_inputs = M->ch[0]->num_inputs;
   parent->has_key = true;
+  parent->peer_state = peer_state;
   *out = parent;
   return G16_OK;
 }
@@ -407,11 +474,25 @@ g16_status multi_prove(g16_ctx* parent, const uint64_t r[4], const uint64_t s_[4
       rank_phase2_enqueue(M.ch[g], M.dv[g]->recv[0].p, M.dv[g]->send[1].p);
       push_chunks(M, g, 1);
     });
-    st.push_back([&](int g) {
-      G16_HIP(hipSetDevice(M.ch[g]->device));
-      await_chunks(M, g, 1, M.ch[g]->aux);
-      rank_phase3_enqueue(M.ch[g], M.dv[g]->recv[1].p);
-    });
+    if (M.buckets) {
+      st.push_back([&](int g) {
+        G16_HIP(hipSetDevice(M.ch[g]->device));
+        await_chunks(M, g, 1, M.ch[g]->aux);
+        rank_phase3h_enqueue(M.ch[g], M.dv[g]->recv[1].p, nullptr);
+        push_h(M, g);
+      });
+      st.push_back([&](int g) {
+        G16_HIP(hipSetDevice(M.ch[g]->device));
+        await_chunks(M, g, 2, M.ch[g]->aux);
+        rank_phase4_enqueue(M.ch[g], nullptr);
+      });
+    } else {
+      st.push_back([&](int g) {
+        G16_HIP(hipSetDevice(M.ch[g]->device));
+        await_chunks(M, g, 1, M.ch[g]->aux);
+        rank_phase3_enqueue(M.ch[g], M.dv[g]->recv[1].p);
+      });
+    }
   } else {
     st.push_back([&](int g) {
       stage_witness(g);

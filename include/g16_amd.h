@@ -73,8 +73,20 @@ typedef struct {
   int planes;      /* stored multiples 2^(c*D*j)P per point; <= 0: as many as fit (full = W)     */
   int dist_wm;     /* world > 1 only: distribute the witness map too (g16_prove_dist_phase*)      */
   int reduction;   /* G16_REDUCTION_CIRCOM (0, default) or G16_REDUCTION_LIBSNARK                  */
-  int reserved[1];
+  int shard;       /* world > 1: G16_SHARD_AUTO (0), G16_SHARD_POINTS, G16_SHARD_BUCKETS (below)    */
 } g16_options;
+
+/* How the MSMs of one proof are cut over `world` ranks:
+ *   POINTS   every query array by contiguous point range; a rank sorts and accumulates its n/world
+ *            points with the window that suits n/world (more windows, a bucket set per rank);
+ *   BUCKETS  every rank keeps the whole key resident (sized for 288 GB: 21 GiB at 2^22, 84 GiB at
+ *            2^24) and the single-GPU window; the sorted (bucket, point) list is cut into `world`
+ *            equal runs of whole sort partitions, chosen on the device from the digit histogram, and
+ *            rank g accumulates and reduces run g only.  Same additions per point as on one GPU,
+ *            1/world of the bucket reduction per rank, and no bucket sums on the links: the only MSM
+ *            traffic is the 1 KiB record per rank (plus the all-gather of h, 32 n bytes per rank).
+ *   AUTO     BUCKETS when the full planes of the whole key fit the device, else POINTS.            */
+enum { G16_SHARD_AUTO = 0, G16_SHARD_POINTS = 1, G16_SHARD_BUCKETS = 2 };
 
 /* The R1CS -> QAP reduction (the `QAP` type parameter of ark_groth16::Groth16<E, QAP>):
  *   CIRCOM   = ark_circom::CircomReduction (reference src/circom/qap.rs:12-106): snarkjs keys (.zkey)
@@ -189,6 +201,19 @@ g16_status g16_prove_dist_phase2(g16_ctx* ctx, const void* recv_dev, void* send_
 g16_status g16_prove_dist_phase3(g16_ctx* ctx, const void* recv_dev,
                                  uint8_t partial_out[G16_PARTIAL_BYTES]);
 
+/* Bucket-sharded ranks (options.shard = G16_SHARD_BUCKETS, or AUTO when the whole key fits): the H MSM
+ * needs all n h scalars on every rank, so phase 3 is followed by an all-gather and a fourth phase:
+ *   ... exchange 2 -> phase3h(recv, h_send) -> all-gather of g16_dist_h_bytes() bytes per rank
+ *   -> phase4(h_all, partial_out) -> all-gather of the partial records -> g16_prove_finish[_dev].
+ * h_send NULL: the rank's slice of g16_h_gather_buffer() (n x 32 bytes, rank order) -- an in-place
+ * all-gather (ncclAllGather with sendbuff = recvbuff + rank * count) then needs no copy; h_all NULL:
+ * that same buffer.  The H query is held in the order the all-gather delivers the scalars.         */
+size_t g16_dist_h_bytes(const g16_ctx* ctx);
+void* g16_h_gather_buffer(g16_ctx* ctx);
+g16_status g16_prove_dist_phase3h(g16_ctx* ctx, const void* recv_dev, void* h_send_dev);
+g16_status g16_prove_dist_phase4(g16_ctx* ctx, const void* h_all_dev,
+                                 uint8_t partial_out[G16_PARTIAL_BYTES]);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
 #define G16_N_STAGES 7
 g16_status g16_set_profiling(g16_ctx* ctx, int enabled);
@@ -197,7 +222,9 @@ g16_status g16_stage_times(g16_ctx* ctx, float ms[G16_N_STAGES], uint32_t launch
 const char* g16_stage_name(int stage);
 /* sizes chosen at create time: out[0]=c_w out[1]=W_w out[2]=planes_w out[3]=D_w, [4..7] same for H,
  * out[8] = domain_size, out[9] = log2(domain_size), out[10] / out[11] = points of the witness / H
- * shard (rank 0's for a multi-device ctx), out[12] = devices                                     */
+ * shard (rank 0's for a multi-device ctx), out[12] = devices, out[13] = how a world > 1 ctx shards
+ * (G16_SHARD_POINTS / G16_SHARD_BUCKETS; 0 for world = 1), out[14] = multi-device ctx: 1 when every
+ * pair of its devices has direct peer access, 2 when some exchanges are staged by the runtime      */
 g16_status g16_ctx_info(const g16_ctx* ctx, uint32_t out[16]);
 /* device pointer of the ctx's witness staging buffer (n_vars x 32 bytes) for g16_prove_dev        */
 void* g16_witness_buffer(g16_ctx* ctx);

@@ -1,11 +1,16 @@
 """Projected strong-scaling efficiency T1 / (G x T_rank) on ONE MI355X (the only hardware available
-to the builder): the single-GPU proof and ONE rank of the fully sharded prover (rank 0 of G) are timed
-on the same box with the same library.  The rank runs exactly what it runs on an 8-GPU node --
-phases 1-3 with the device-side hand-offs (g16_dist_set_exchange_stream: no host syncs), its MSM
-shards, the partial record and the finish -- except that the two all-to-all exchanges and the
-all-gather are replaced by local copies of the same byte counts on the exchange stream (xGMI time is
-therefore NOT in T_rank: 3n/G x 36 B per rank and exchange).
-    python scripts/dist_projection.py [log2=22] [worlds=2,4,8] [reps=5]"""
+to the builder): the single-GPU proof and ONE rank of the fully sharded prover are timed on the same
+box with the same library.  The rank runs exactly what it runs on an 8-GPU node -- the witness-map
+phases with the device-side hand-offs (g16_dist_set_exchange_stream: no host syncs), its share of the
+MSMs, the partial record and the finish -- except that the exchanges are replaced by local copies
+of the same byte counts on the exchange stream.  xGMI time is therefore NOT in T_rank; the bytes a
+rank sends per proof and the link time they take at a stated per-link rate are printed beside it.
+
+    python scripts/dist_projection.py [log2=22] [worlds=2,4,8] [reps=5] [modes=points,buckets]
+
+modes: points  = MSMs cut by point range (rank 0 is timed: all ranks alike)
+       buckets = MSMs cut by bucket range (every rank holds the whole key; the slowest of rank 0 --
+                 the dense low partitions, fewest buckets -- and a middle rank is reported)"""
 import json
 import os
 import random
@@ -23,6 +28,8 @@ import circom_compat_amd as cc
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 worlds = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "2,4,8").split(",")]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+modes = (sys.argv[4] if len(sys.argv) > 4 else "points,buckets").split(",")
+LINK_GBS = float(os.environ.get("G16_PROJ_LINK_GBS", "48"))   # one xGMI link, one direction, achieved
 t0 = time.time()
 mats, (A, B, Cm), w_ints, n_vars = bench.chain_circuit(cc, k)
 rng = random.Random(k)
@@ -54,17 +61,29 @@ else:
     info1 = single.info()
     single.close()
     del single
-out = {"log2": k, "single_gpu_ms": t1, "single_msm": {x: info1[x] for x in ("c_w", "W_w")}, "ranks": {}}
+out = {"log2": k, "single_gpu_ms": t1, "single_msm": {x: info1[x] for x in ("c_w", "W_w")},
+       "link_GBs_assumed": LINK_GBS, "ranks": {}}
 # high priority: shares a hardware queue with the aux stream, not with the MSM streams (G16_PROJ_XS_PRIO=0: A/B)
 xs = torch.cuda.Stream(priority=-1 if os.environ.get('G16_PROJ_XS_PRIO', '1') != '0' else 0)
-for G in worlds:
-    p = cc.Prover(pk, mats, rank=0, world=G, dist_wm=True)
+
+
+def one_rank(G, mode, rank):
+    p = cc.Prover(pk, mats, rank=rank, world=G, dist_wm=True, shard=mode)
     p.set_exchange_stream(xs.cuda_stream)
     nbytes = p.exchange_bytes()
     send = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
     recv = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
     part = cc.device_tensor(p.partial_buffer(), 1024)
     gath = cc.device_tensor(p.gather_buffer(), G * 1024)
+    hb = p.h_bytes()
+    if mode == "buckets":
+        # the other ranks' h scalars: uniform 253-bit values (what the sort and the H MSM see on a real node)
+        h_all = cc.device_tensor(p.h_gather_buffer(), G * hb)
+        fill = torch.randint(0, 1 << 62, (G * hb // 8,), dtype=torch.int64, device="cuda")
+        fill[3::4] &= (1 << 60) - 1
+        h_all.copy_(fill.view(torch.uint8))
+        h_tmp = torch.empty(hb, dtype=torch.uint8, device="cuda")
+        del fill
 
     def rank_step():
         p.dist_phase1(rs[0], rs[1], w_dev.data_ptr(), send.data_ptr())
@@ -73,7 +92,14 @@ for G in worlds:
         p.dist_phase2(recv.data_ptr(), send.data_ptr())
         with torch.cuda.stream(xs):
             recv.copy_(send, non_blocking=True)
-        p.dist_phase3_dev(recv.data_ptr())
+        if mode == "points":
+            p.dist_phase3_dev(recv.data_ptr())
+        else:
+            p.dist_phase3h(recv.data_ptr())
+            with torch.cuda.stream(xs):          # stands in for the G - 1 slices arriving from the peers
+                for g in range(G - 1):
+                    h_tmp.copy_(h_all[g * hb:(g + 1) * hb], non_blocking=True)
+            p.dist_phase4_dev()
         with torch.cuda.stream(xs):
             for g in range(G):
                 gath[g * 1024:(g + 1) * 1024].copy_(part, non_blocking=True)
@@ -81,10 +107,28 @@ for G in worlds:
 
     tr = timed(rank_step)
     info = p.info()
-    out["ranks"][str(G)] = {"per_rank_ms": tr, "efficiency_before_xgmi": t1 / (G * tr),
-                            "exchange_MB_per_rank": nbytes / 1e6, "c_w": info["c_w"], "W_w": info["W_w"],
-                            "shard_w": info["shard_w"]}
+    p.set_profiling(True)
+    rank_step()
+    torch.cuda.synchronize()
+    stages = {n: round(ms, 3) for n, (ms, _c) in p.stage_times().items()}
     p.close()
-    del p, send, recv
-    torch.cuda.empty_cache()
+    # bytes this rank SENDS per proof: (G-1)/G of each all-to-all buffer, its h slice to G-1 peers
+    sent = 2 * nbytes * (G - 1) / G + (hb * (G - 1) if mode == "buckets" else 0)
+    links = min(G - 1, 7)
+    return tr, info, stages, sent, sent / links / (LINK_GBS * 1e9) * 1e3
+
+
+for mode in modes:
+    for G in worlds:
+        cand = [0] if mode == "points" else sorted({0, G // 2})
+        res = [one_rank(G, mode, r) for r in cand]
+        tr, info, stages, sent, link_ms = max(res, key=lambda x: x[0])
+        out["ranks"][f"{mode}:{G}"] = {
+            "mode": mode, "G": G, "per_rank_ms": tr, "ranks_timed": {str(r): x[0] for r, x in zip(cand, res)},
+            "efficiency_before_xgmi": t1 / (G * tr),
+            "sent_MB_per_rank_per_proof": sent / 1e6, "link_ms_if_exposed": link_ms,
+            "efficiency_if_all_link_time_exposed": t1 / (G * (tr + link_ms)),
+            "c_w": info["c_w"], "W_w": info["W_w"], "shard_w": info["shard_w"],
+            "stages_ms_alone": stages}
+        torch.cuda.empty_cache()
 print(json.dumps(out))

@@ -36,7 +36,8 @@ extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 typedef int hipError_t;
 typedef struct emuStream* hipStream_t;
 typedef struct emuEvent* hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorPeerAccessUnsupported = 217,
+       hipErrorPeerAccessAlreadyEnabled = 704 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 #define hipStreamNonBlocking 1
 #define hipEventDisableTiming 2
@@ -105,6 +106,7 @@ static inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s,
 }
 static inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t = 0) { if (n) memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = 0) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }

@@ -1,5 +1,6 @@
-"""world_size = 2 and 4 over gloo on the CPU: the sharded path (per-rank point-range MSM partials ->
-all_gather -> local EC add -> finish) gives the same proof bytes as the single-rank path.
+"""world_size = 2 and 4 over gloo on the CPU: the sharded paths (per-rank MSM partials over point
+ranges and over bucket ranges -> all_gather -> local EC add -> finish; distributed witness map with
+its all-to-all exchanges and, for bucket ranges, the all-gather of h) give the oracle's proof bytes.
 Runs the kernel sources on the SIMT emulator (tests only); on the GPU the same harness code in
 bench.py uses backend nccl (= RCCL)."""
 import os
@@ -37,7 +38,7 @@ WORKER = textwrap.dedent('''
     mats = H.matrices_from_rows(a_rows, b_rows, ni, n_vars, lib)
     pk = H.pk_from_oracle(opk)
     r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
-    pr = cc.Prover(pk, mats, lib=lib, rank=rank, world=world)
+    pr = cc.Prover(pk, mats, lib=lib, rank=rank, world=world, shard="points")
     part = pr.prove_partial(r, s, w)
     mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
     gathered = torch.empty(world * 1024, dtype=torch.uint8)
@@ -46,7 +47,7 @@ WORKER = textwrap.dedent('''
     want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), ni, len(cons), w)
     assert proof.raw == o.proof_to_bytes(want), "sharded proof differs from the oracle"
     # fully sharded: the witness map is distributed too (four-step NTTs, two all-to-all exchanges)
-    pd = cc.Prover(pk, mats, lib=lib, rank=rank, world=world, dist_wm=True)
+    pd = cc.Prover(pk, mats, lib=lib, rank=rank, world=world, dist_wm=True, shard="points")
     nbytes = pd.exchange_bytes()
     send = torch.empty(nbytes, dtype=torch.uint8)
     recv = torch.empty(nbytes, dtype=torch.uint8)
@@ -61,6 +62,32 @@ WORKER = textwrap.dedent('''
     proof2 = pd.prove_finish(r, s, g2.numpy().tobytes())
     assert proof2.raw == o.proof_to_bytes(want), "fully sharded proof differs from the oracle"
     assert o.verify_proof(opk, w[1:ni], H.proof_from_bytes(proof.raw))
+    # MSMs sharded by BUCKET range (every rank holds the whole key, keeps 1/world of the sorted list):
+    # replicated witness map first ...
+    pb = cc.Prover(pk, mats, lib=lib, rank=rank, world=world, shard="buckets")
+    assert pb.info()["shard_mode"] == "buckets" and pb.info()["shard_w"] == n_vars - 1
+    g3 = torch.empty(world * 1024, dtype=torch.uint8)
+    dist.all_gather_into_tensor(g3, torch.frombuffer(bytearray(pb.prove_partial(r, s, w)), dtype=torch.uint8))
+    assert pb.prove_finish(r, s, g3.numpy().tobytes()).raw == o.proof_to_bytes(want), "bucket-sharded proof differs"
+    # ... then fully sharded: phases 1-2 as above, phase 3 leaves this rank's h scalars, all-gather of
+    # h, phase 4 = the rank's share of the H MSM
+    pq = cc.Prover(pk, mats, lib=lib, rank=rank, world=world, dist_wm=True, shard="buckets")
+    nbytes = pq.exchange_bytes()
+    send = torch.empty(nbytes, dtype=torch.uint8)
+    recv = torch.empty(nbytes, dtype=torch.uint8)
+    pq.dist_phase1(r, s, w_arr.ctypes.data, send.data_ptr())
+    dist.all_to_all_single(recv, send)
+    pq.dist_phase2(recv.data_ptr(), send.data_ptr())
+    dist.all_to_all_single(recv, send)
+    h_mine = torch.empty(pq.h_bytes(), dtype=torch.uint8)
+    h_all = torch.empty(world * pq.h_bytes(), dtype=torch.uint8)
+    assert h_all.numel() == 32 * pk.domain_size
+    pq.dist_phase3h(recv.data_ptr(), h_mine.data_ptr())
+    dist.all_gather_into_tensor(h_all, h_mine)
+    part4 = pq.dist_phase4(h_all.data_ptr())
+    g4 = torch.empty(world * 1024, dtype=torch.uint8)
+    dist.all_gather_into_tensor(g4, torch.frombuffer(bytearray(part4), dtype=torch.uint8))
+    assert pq.prove_finish(r, s, g4.numpy().tobytes()).raw == o.proof_to_bytes(want), "fully bucket-sharded proof differs"
     # every rank must have produced the identical proof
     t = torch.frombuffer(bytearray(proof.raw), dtype=torch.uint8).clone()
     ref = t.clone()

@@ -132,24 +132,29 @@ def test_determinism(gpulib, golden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shard", ["points", "buckets"])
 @pytest.mark.parametrize("logm,world", [(10, 2), (14, 4), (16, 8)])
-def test_fully_sharded_prover_emulated_ranks_one_gpu(gpulib, logm, world):
-    """The fully sharded prover (distributed witness map + point-range MSM shards) with all `world`
-    ranks living on ONE GPU: the two all-to-all exchanges are done by hand on device tensors.
-    The proof must be bit-identical to the single-rank proof of the same (pk, r, s, w)."""
+def test_fully_sharded_prover_emulated_ranks_one_gpu(gpulib, logm, world, shard):
+    """The fully sharded prover through the per-process API (distributed witness map + MSMs sharded by
+    point range or by bucket range) with all `world` ranks living on ONE GPU: the all-to-all exchanges
+    (and the all-gather of h under bucket ranges) are done by hand on device tensors.  The proof must
+    be bit-identical to the CPU restatement's proof of the same (pk, r, s, w)."""
     import torch
     import circom_compat_amd as cc
+    import cpu_ref
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     import bench
     mats, (A, B, Cm), w_ints, n_vars = bench.chain_circuit(cc, logm)
     rng = random.Random(logm)
     tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
     pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox)
-    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    rs = cc.fr_from_ints([rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)])
+    r, s = rs[0], rs[1]
     w = cc.fr_from_ints(w_ints)
-    single = cc.Prover(pk, mats).prove(r, s, w)
+    want = cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
     w_dev = torch.from_numpy(w.view(np.int64)).cuda()
-    provers = [cc.Prover(pk, mats, rank=g, world=world, dist_wm=True) for g in range(world)]
+    provers = [cc.Prover(pk, mats, rank=g, world=world, dist_wm=True, shard=shard) for g in range(world)]
+    assert all(p.info()["shard_mode"] == shard for p in provers)
     nbytes = provers[0].exchange_bytes()
     send = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(world)]
     recv = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(world)]
@@ -167,13 +172,19 @@ def test_fully_sharded_prover_emulated_ranks_one_gpu(gpulib, logm, world):
     for g, p in enumerate(provers):
         p.dist_phase2(recv[g].data_ptr(), send[g].data_ptr())
     all_to_all()
-    parts = b"".join(p.dist_phase3(recv[g].data_ptr()) for g, p in enumerate(provers))
+    if shard == "points":
+        parts = b"".join(p.dist_phase3(recv[g].data_ptr()) for g, p in enumerate(provers))
+    else:
+        hb = provers[0].h_bytes()
+        assert hb * world == 32 * pk.domain_size
+        h_all = torch.empty(hb * world, dtype=torch.uint8, device="cuda")
+        for g, p in enumerate(provers):                       # all-gather: every rank's slice, rank order
+            p.dist_phase3h(recv[g].data_ptr(), h_all[g * hb:(g + 1) * hb].data_ptr())
+        torch.cuda.synchronize()
+        parts = b"".join(p.dist_phase4(h_all.data_ptr()) for p in provers)
     proof = provers[0].prove_finish(r, s, parts)
-    assert proof.raw == single.raw
-    vk = dict(alpha_g1=o.g1_from_bytes(bytes(pk.vk.alpha_g1)), beta_g2=o.g2_from_bytes(bytes(pk.vk.beta_g2)),
-              gamma_g2=o.g2_from_bytes(bytes(pk.vk.gamma_g2)), delta_g2=o.g2_from_bytes(bytes(pk.vk.delta_g2)),
-              ic=[o.g1_from_bytes(bytes(x)) for x in pk.vk.gamma_abc_g1])
-    assert o.verify_proof(vk, [w_ints[1]], H.proof_from_bytes(proof.raw))
+    assert proof.raw == want
+    assert o.verify_proof(_vk_dict(pk), [w_ints[1]], H.proof_from_bytes(proof.raw))
 
 
 @pytest.mark.gpu
@@ -291,10 +302,26 @@ def test_full_prove_headline_sizes_bytes_pairing_and_qap_identities(gpulib, k):
     W = -sum(xs[j + 1] * L[j] for j in range(m)) % R
     assert lhs == (U * V - W) * di % R, "QAP identity fails on the GPU witness map"
     assert pr.msm_g1(3, cc.fr_from_ints(h)) == o.g1_to_bytes(o.G1.mul(o.G1_GEN, lhs))
+    # ---- BASELINE configs[3] as far as one GPU allows: the SAME circuit sharded over 8 ranks
+    # (g16_ctx_create_multi, every rank on this GPU, MSMs cut by bucket range, distributed witness
+    # map, h all-gather): bytes == the CPU proof above; a second proof with other (r, s) verifies
+    if k >= 22:
+        pr.close()
+        del pr
+        multi = cc.Prover(pk, mats, devices=[0] * 8, shard="buckets")
+        info = multi.info()
+        assert (info["devices"], info["shard_mode"], info["shard_w"]) == (8, "buckets", n_vars - 1)
+        wptr = multi.upload_witness(w)
+        assert multi.prove_dev(rs[0], rs[1], wptr).raw == want, "8-rank bucket-sharded proof differs at 2^%d" % k
+        rs2 = cc.fr_from_ints([rs_rng.randrange(R), rs_rng.randrange(R)])
+        p2 = multi.prove_dev(rs2[0], rs2[1], wptr)
+        assert p2.raw != want and o.verify_proof(vk, [w_ints[1]], H.proof_from_bytes(p2.raw))
+        multi.close()
 
 
-@pytest.mark.parametrize("logm,world", [(14, 4), (17, 8), (22, 8)])
-def test_in_library_multi_device_prover_large(gpulib, logm, world):
+@pytest.mark.parametrize("logm,world,shard", [(14, 4, "points"), (14, 4, "buckets"), (17, 8, "buckets"),
+                                              (17, 3, "buckets"), (22, 8, "points")])
+def test_in_library_multi_device_prover_large(gpulib, logm, world, shard):
     """g16_ctx_create_multi with every rank on this one GPU (device_ids = [0] * world): the exchanges,
     events and per-device host threads of csrc/multi.hip are the real ones (only the peer copies
     degenerate to device-local copies).  Two consecutive proofs with different (r, s): bytes == the
@@ -308,8 +335,8 @@ def test_in_library_multi_device_prover_large(gpulib, logm, world):
     tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
     pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox)
     w = cc.fr_from_ints(w_ints)
-    pr = cc.Prover(pk, mats, devices=[0] * world)
-    assert pr.info()["devices"] == world
+    pr = cc.Prover(pk, mats, devices=[0] * world, shard=shard)
+    assert pr.info()["devices"] == world and pr.info()["shard_mode"] == shard
     host = pr.witness_host_buffer()                     # pinned staging buffer owned by the ctx
     host[:] = w
     for _ in range(2 if logm < 20 else 1):              # headline size: one CPU proof (~16 s) is enough
@@ -320,7 +347,8 @@ def test_in_library_multi_device_prover_large(gpulib, logm, world):
     pr.close()
 
 
-def test_per_rank_api_with_exchange_stream_no_host_syncs(gpulib):
+@pytest.mark.parametrize("shard", ["points", "buckets"])
+def test_per_rank_api_with_exchange_stream_no_host_syncs(gpulib, shard):
     """The per-process API driven the way bench.py drives it under torchrun, with the collectives'
     stream registered (g16_dist_set_exchange_stream): the phase calls never block the host, every
     hand-off is an event.  world = 4 ranks on this one GPU, the all-to-all / all-gather done by hand
@@ -339,9 +367,10 @@ def test_per_rank_api_with_exchange_stream_no_host_syncs(gpulib):
     w_dev = torch.from_numpy(w.view(np.int64)).cuda()
     torch.cuda.synchronize()
     xs = torch.cuda.Stream(priority=-1)   # high priority: shares a hardware queue with the aux stream, not with the MSM streams
-    provers = [cc.Prover(pk, mats, rank=g, world=world, dist_wm=True) for g in range(world)]
+    provers = [cc.Prover(pk, mats, rank=g, world=world, dist_wm=True, shard=shard) for g in range(world)]
     for p in provers:
         p.set_exchange_stream(xs.cuda_stream)
+    hb = provers[0].h_bytes()
     nbytes = provers[0].exchange_bytes()
     chunk = nbytes // world
     send = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(world)]
@@ -362,8 +391,22 @@ def test_per_rank_api_with_exchange_stream_no_host_syncs(gpulib):
         for g, p in enumerate(provers):
             p.dist_phase2(recv[g].data_ptr(), send[g].data_ptr())
         all_to_all()
-        for g, p in enumerate(provers):
-            p.dist_phase3_dev(recv[g].data_ptr())
+        if shard == "points":
+            for g, p in enumerate(provers):
+                p.dist_phase3_dev(recv[g].data_ptr())
+        else:
+            for g, p in enumerate(provers):                 # h shard left in the rank's own slice
+                p.dist_phase3h(recv[g].data_ptr())
+            with torch.cuda.stream(xs):                     # all-gather of h, device to device
+                for dst in provers:
+                    out = cc.device_tensor(dst.h_gather_buffer(), world * hb)
+                    for g, src in enumerate(provers):
+                        if src is not dst:
+                            out[g * hb:(g + 1) * hb].copy_(
+                                cc.device_tensor(src.h_gather_buffer(), world * hb)[g * hb:(g + 1) * hb],
+                                non_blocking=True)
+            for p in provers:
+                p.dist_phase4_dev()
         # all-gather of the 1 KiB records, device to device on the registered stream
         with torch.cuda.stream(xs):
             for dst in provers:
@@ -430,3 +473,83 @@ def test_dense_skewed_2p20_through_zkey_vs_cpu_restatement(gpulib, tmp_path):
     proof = cc.Prover(pk, mats).prove(rs[0], rs[1], w)
     assert proof.raw == cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
     assert o.verify_proof(_vk_dict(pk), [w_ints[1]], H.proof_from_bytes(proof.raw))
+
+
+RCCL_WORKER = r'''
+import os, sys, random
+import numpy as np
+import torch, torch.distributed as dist
+ROOT = sys.argv[1]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import bench, cpu_ref
+import circom_compat_amd as cc
+logm = int(sys.argv[2])
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+mats, (A, B, Cm), w_ints, n_vars = bench.chain_circuit(cc, logm)
+rng = random.Random(logm)
+tox = [rng.randrange(1, bench.R_MOD) for _ in range(5)]
+pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox)
+w = cc.fr_from_ints(w_ints)
+w_dev = torch.from_numpy(w.view(np.int64)).cuda()
+torch.cuda.synchronize()
+xs = torch.cuda.Stream(priority=-1)      # the collectives' stream, registered with the library
+for shard in ("points", "buckets"):
+    p = cc.Prover(pk, mats, rank=0, world=1, dist_wm=True, shard=shard)
+    p.set_exchange_stream(xs.cuda_stream)
+    nbytes = p.exchange_bytes()
+    send = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    recv = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    part_t = cc.device_tensor(p.partial_buffer(), 1024)
+    gath_t = cc.device_tensor(p.gather_buffer(), 1024)
+    for it in range(2):
+        rs = cc.fr_from_ints([rng.randrange(bench.R_MOD), rng.randrange(bench.R_MOD)])
+        p.dist_phase1(rs[0], rs[1], w_dev.data_ptr(), send.data_ptr())
+        with torch.cuda.stream(xs):
+            dist.all_to_all_single(recv, send)
+        p.dist_phase2(recv.data_ptr(), send.data_ptr())
+        with torch.cuda.stream(xs):
+            dist.all_to_all_single(recv, send)
+        if shard == "points":
+            p.dist_phase3_dev(recv.data_ptr())
+        else:
+            hb = p.h_bytes()
+            h_mine = torch.empty(hb, dtype=torch.uint8, device="cuda")
+            h_all = torch.empty(hb, dtype=torch.uint8, device="cuda")
+            p.dist_phase3h(recv.data_ptr(), h_mine.data_ptr())
+            with torch.cuda.stream(xs):
+                dist.all_gather_into_tensor(h_all, h_mine)
+            p.dist_phase4_dev(h_all.data_ptr())
+        with torch.cuda.stream(xs):
+            dist.all_gather_into_tensor(gath_t, part_t)
+        proof = p.prove_finish_dev(rs[0], rs[1])
+        want = cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
+        assert proof.raw == want, f"{shard}: proof {it} differs from the CPU restatement"
+    p.close()
+torch.cuda.synchronize()
+print("rccl backend:", dist.get_backend(), "ok")
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_executes_next_to_the_library_world1(gpulib, tmp_path):
+    """RCCL (torch backend "nccl") loaded and executing in the same process as libg16_amd.so: a
+    one-rank process group drives the per-process phase API -- all_to_all_single twice,
+    all_gather_into_tensor of h (bucket mode) and of the 1 KiB records -- on the registered
+    high-priority stream, with the library's event hand-offs on both sides of every collective.
+    Degenerate exchanges (one rank), real code path: the first 8-GPU run is not the first time the
+    two libraries meet.  bytes == CPU restatement, two consecutive proofs per shard mode."""
+    import socket
+    import subprocess
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               TORCH_NCCL_HIGH_PRIORITY="1")
+    r = subprocess.run([sys.executable, str(script), root, "15"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "rccl backend: nccl ok" in r.stdout

@@ -440,13 +440,15 @@ def test_error_paths_through_the_abi(lib, golden):
     assert len(pr.prove(1, 2, [1, 33, 3, 11]).raw) == 256
 
 
+@pytest.mark.parametrize("shard", ["points", "buckets"])
 @pytest.mark.parametrize("logm,devices", [(4, [0, 0]), (5, [0, 0, 0, 0]), (4, [0, 0, 0])])
-def test_in_library_multi_device_prover(lib, logm, devices):
-    """g16_ctx_create_multi: one ctx, the ranks (point-range MSM shards + distributed witness map for
-    power-of-two device counts, replicated witness map otherwise) and BOTH all-to-all exchanges and
-    the gather live inside the library -- no host framework, no collective library.  Every listed
-    device is ordinal 0 here (ranks time-sharing one device); the proof must equal the oracle's, and
-    two consecutive proofs with different (r, s) cover buffer / event reuse."""
+def test_in_library_multi_device_prover(lib, logm, devices, shard):
+    """g16_ctx_create_multi: one ctx, the ranks (MSMs sharded by point range or by bucket range +
+    distributed witness map for power-of-two device counts, replicated witness map otherwise) and
+    every exchange (two all-to-all, the all-gather of h under bucket ranges) and the gather live
+    inside the library -- no host framework, no collective library.  Every listed device is ordinal 0
+    here (ranks time-sharing one device; bucket-sharded ranks borrow rank 0's planes); the proof must
+    equal the oracle's, and two consecutive proofs with different (r, s) cover buffer / event reuse."""
     import circom_compat_amd as cc
     cons, w, n_vars, n_pub = H.squaring_chain(logm)
     rng = random.Random(logm)
@@ -455,8 +457,10 @@ def test_in_library_multi_device_prover(lib, logm, devices):
     a_rows, b_rows = o.matrices_from_r1cs(cons)
     mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, lib)
     pk = H.pk_from_oracle(opk)
-    pr = cc.Prover(pk, mats, lib=lib, devices=devices)
+    pr = cc.Prover(pk, mats, lib=lib, devices=devices, shard=shard)
     assert pr.info()["devices"] == len(devices)
+    assert pr.info()["shard_mode"] == shard and pr.info()["peer_access"] == 1
+    assert pr.info()["shard_w"] == (n_vars - 1 if shard == "buckets" else (n_vars - 1) // len(devices))
     for _ in range(2):
         r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
         want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2, len(cons), w)
@@ -554,8 +558,9 @@ def test_domain_too_large_and_bad_matrices(lib):
         cc.Prover(None, cc.ConstraintMatrices(2, 2, 1, ok, ok), lib=lib)     # n_vars is required
 
 
+@pytest.mark.parametrize("shard", ["points", "buckets"])
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0, 0, 0, 0]])
-def test_multi_device_prover_on_the_reference_zkey(lib, golden, devices):
+def test_multi_device_prover_on_the_reference_zkey(lib, golden, devices, shard):
     """test.zkey (4 wires, domain 4) through read_zkey -- zero-copy, UNALIGNED views of the file's point
     sections -- on 2 / 3 / 4 ranks: shards of one or zero points, the smallest four-step split
     (n1 = n2 = 2), bytes == oracle (SURVEY C.1 inputs)."""
@@ -567,7 +572,7 @@ def test_multi_device_prover_on_the_reference_zkey(lib, golden, devices):
     r = 3413513218498352040262653353725127729454431939539290118844322056224532443637
     s = 6077776500692565155461894309070795882353485867345896979329447163197530625403
     want = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, r, s, omats, 2, 1, w))
-    pr = cc.Prover(pk, mats, lib=lib, devices=devices)
+    pr = cc.Prover(pk, mats, lib=lib, devices=devices, shard=shard)
     assert pr.prove(r, s, w).raw == want
     assert pr.prove(0, 0, w).raw == o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, 0, 0, omats, 2, 1, w))
     pr.close()
@@ -594,7 +599,43 @@ def test_no_public_inputs_and_single_constraint(lib, n_pub, m):
     r, s = rng.randrange(P), rng.randrange(P)
     want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), n_pub + 1, m, w)
     assert o.verify_proof(opk, w[1:1 + n_pub], want)
-    for devices in (None, [0, 0]):
-        pr = cc.Prover(pk, mats, lib=lib, devices=devices)
+    for devices, shard in ((None, "auto"), ([0, 0], "points"), ([0, 0], "buckets")):
+        pr = cc.Prover(pk, mats, lib=lib, devices=devices, shard=shard)
         assert pr.prove(r, s, w).raw == o.proof_to_bytes(want)
         pr.close()
+
+
+@pytest.mark.parametrize("logm,world,wb,planes,kind", [(5, 4, 13, 0, "dense"), (6, 8, 14, 3, "chain"),
+                                                     (4, 3, 12, 0, "dense"), (5, 2, 0, 1, "chain")])
+def test_bucket_range_sharding_windows_planes_and_skew(lib, logm, world, wb, planes, kind):
+    """MSMs sharded by BUCKET range (g16_options.shard = G16_SHARD_BUCKETS): every rank sorts all
+    scalars but keeps its run of sort partitions, accumulates and reduces that run only.  Covered:
+    windows large enough for multi-bucket partitions (c = 13, 14: the reduction's chunk grid anchored
+    at the run start), fewer planes than windows (several bucket sets, D = 7, D = W: a run spans
+    sets), a skewed 0/1-heavy witness (one partition holds most entries: a rank may own one partition
+    or none), world = 3 (replicated witness map, no h all-gather), 8 ranks on 64 points.  bytes ==
+    oracle, two proofs."""
+    import circom_compat_amd as cc
+    if lib.path.endswith("libg16_emu.so") and wb >= 14 and world >= 8:
+        world = 4                                    # the emulator steps through every rank's 2^13-bucket sets
+    if kind == "dense":
+        cons, w, n_vars, _ = H.dense_skewed_circuit((1 << logm) - 5, seed=3, long_rows=(7,))
+        n_pub = 1
+    else:
+        cons, w, n_vars, n_pub = H.squaring_chain(logm)
+    rng = random.Random(100 * logm + world)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    opk = o.trapdoor_setup(cons, n_vars, n_pub, *tox)
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, n_pub + 1, n_vars, lib)
+    pr = cc.Prover(H.pk_from_oracle(opk), mats, lib=lib, devices=[0] * world, shard="buckets",
+                   window_bits=wb, planes=planes)
+    info = pr.info()
+    assert info["shard_mode"] == "buckets" and info["shard_w"] == n_vars - 1 and info["shard_h"] == info["domain_size"]
+    if wb:
+        assert info["c_w"] == wb
+    for _ in range(2):
+        r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+        want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), n_pub + 1, len(cons), w)
+        assert pr.prove(r, s, w).raw == o.proof_to_bytes(want)
+    pr.close()
