@@ -69,7 +69,7 @@ def _csr(rp, col, coeff):
     return c
 
 
-def witness_map(a, b, num_inputs, m, w):
+def witness_map(a, b, num_inputs, m, w, reduction="circom"):
     """a, b: objects with row_ptr/col/coeff numpy arrays (Montgomery); w (N,4) uint64 Montgomery"""
     need = m + num_inputs
     n = 1
@@ -78,8 +78,9 @@ def witness_map(a, b, num_inputs, m, w):
     h = np.empty((n, 4), dtype=np.uint64)
     dom = C.c_uint32()
     ca, cb = _csr(a.row_ptr, a.col, a.coeff), _csr(b.row_ptr, b.col, b.coeff)
-    st = lib().g16cpu_witness_map(C.byref(ca), C.byref(cb), C.c_uint32(num_inputs), C.c_uint32(m),
-                                  C.c_void_p(w.ctypes.data), C.c_void_p(h.ctypes.data), C.byref(dom))
+    fn = lib().g16cpu_witness_map_libsnark if reduction == "libsnark" else lib().g16cpu_witness_map
+    st = fn(C.byref(ca), C.byref(cb), C.c_uint32(num_inputs), C.c_uint32(m),
+            C.c_void_p(w.ctypes.data), C.c_void_p(h.ctypes.data), C.byref(dom))
     if st == 2:
         raise ValueError("PolynomialDegreeTooLarge")
     assert st == 0 and dom.value == n
@@ -100,7 +101,7 @@ def msm_g2(bases, scalars_mont):
     return out.tobytes()
 
 
-def prove(pk, mats, r_mont, s_mont, w, want_h=False):
+def prove(pk, mats, r_mont, s_mont, w, want_h=False, reduction="circom"):
     """pk: circom_compat_amd.ProvingKey-like (packed numpy arrays); mats: ConstraintMatrices-like"""
     k = _Key()
     k.n_vars, k.n_public, k.domain_size = pk.n_vars, pk.n_public, pk.domain_size
@@ -115,10 +116,11 @@ def prove(pk, mats, r_mont, s_mont, w, want_h=False):
     cb = _csr(mats.b.row_ptr, mats.b.col, mats.b.coeff)
     out = np.empty(256, dtype=np.uint8)
     h = np.empty((pk.domain_size, 4), dtype=np.uint64) if want_h else None
-    st = lib().g16cpu_prove(C.byref(k), C.byref(ca), C.byref(cb), C.c_uint32(mats.num_constraints),
-                            C.c_void_p(r_mont.ctypes.data), C.c_void_p(s_mont.ctypes.data),
-                            C.c_void_p(w.ctypes.data), C.c_void_p(out.ctypes.data),
-                            C.c_void_p(h.ctypes.data) if want_h else None)
+    st = lib().g16cpu_prove_ex(C.byref(k), C.byref(ca), C.byref(cb), C.c_uint32(mats.num_constraints),
+                               C.c_void_p(r_mont.ctypes.data), C.c_void_p(s_mont.ctypes.data),
+                               C.c_void_p(w.ctypes.data), C.c_void_p(out.ctypes.data),
+                               C.c_void_p(h.ctypes.data) if want_h else None,
+                               C.c_int(1 if reduction == "libsnark" else 0))
     if st == 2:
         raise ValueError("PolynomialDegreeTooLarge")
     assert st == 0, st

@@ -393,6 +393,51 @@ int g16cpu_witness_map(const csr_t* A, const csr_t* B, uint32_t num_inputs, uint
   return 0;
 }
 
+/* ark-groth16 0.5 LibsnarkReduction::witness_map_from_matrices (un-vendored crate: restated from its
+ * published algorithm, as oracle/bn254_ref.py:witness_map_libsnark, which pins this function at
+ * small sizes -- tests/test_oracle.py).  The reference reaches it as the default QAP of
+ * `Groth16<Bn254>` (tests/groth16.rs:9,25-35).  a, b, c on the size-n domain -> coefficients ->
+ * coset g H with g = Fr::GENERATOR = 5 (distribute_powers + fft) -> (a b - c) / Z_H(g) pointwise
+ * -> coset ifft (ifft, then powers of 1/g).  c_i = a_i b_i (the matrices hold A and B only).
+ * h_out: n coefficients, the top one is 0.  Returns 0, or 2 (PolynomialDegreeTooLarge).          */
+int g16cpu_witness_map_libsnark(const csr_t* A, const csr_t* B, uint32_t num_inputs, uint32_t m,
+                                const u64* w, u64* h_out, uint32_t* domain_out) {
+  int k = 0;
+  while (((u64)1 << k) < (u64)m + num_inputs) ++k;
+  if (k > 28) return 2;
+  const size_t n = (size_t)1 << k;
+  if (domain_out) *domain_out = (uint32_t)n;
+  u64* a = (u64*)calloc(n, 32);
+  u64* b = (u64*)calloc(n, 32);
+  u64* c = (u64*)calloc(n, 32);
+  _Pragma("omp parallel for schedule(static)")
+  for (uint32_t i = 0; i < m; ++i) {
+    eval_row(a + 4 * (size_t)i, A, i, w);
+    eval_row(b + 4 * (size_t)i, B, i, w);
+    fp_mul(c + 4 * (size_t)i, a + 4 * (size_t)i, b + 4 * (size_t)i, &FR);
+  }
+  memcpy(a + 4 * (size_t)m, w, (size_t)num_inputs * 32);
+  u64 g[4] = {5, 0, 0, 0}; fp_to_mont(g, g, &FR);
+  fft(a, k, 1); distribute_powers(a, n, g); fft(a, k, 0);
+  fft(b, k, 1); distribute_powers(b, n, g); fft(b, k, 0);
+  fft(c, k, 1); distribute_powers(c, n, g); fft(c, k, 0);
+  /* Z_H(g w^i) = g^n - 1 for every i */
+  u64 zi[4]; memcpy(zi, g, 32);
+  for (int i = 0; i < k; ++i) fp_sqr(zi, zi, &FR);
+  fp_sub(zi, zi, FR.one, &FR); fp_inv(zi, zi, &FR);
+  _Pragma("omp parallel for schedule(static)")
+  for (size_t i = 0; i < n; ++i) {
+    u64 t[4];
+    fp_mul(t, a + 4 * i, b + 4 * i, &FR);
+    fp_sub(t, t, c + 4 * i, &FR);
+    fp_mul(h_out + 4 * i, t, zi, &FR);
+  }
+  u64 gi[4]; fp_inv(gi, g, &FR);
+  fft(h_out, k, 1); distribute_powers(h_out, n, gi);
+  free(a); free(b); free(c);
+  return 0;
+}
+
 static u64* to_canonical(const u64* in, size_t n) {
   u64* out = (u64*)malloc((n ? n : 1) * 32);
   _Pragma("omp parallel for schedule(static)")
@@ -412,16 +457,20 @@ void g16cpu_msm_g2(const uint8_t* bases, const u64* scalars_mont, size_t n, uint
   g2_aff a; g2_to_aff(&a, &r); memcpy(out, &a, 128); free(s);
 }
 
-/* create_proof_with_reduction_and_matrices.  r, s Montgomery.  h_opt: if non-NULL receives h.   */
-int g16cpu_prove(const pkey_t* key, const csr_t* A, const csr_t* B, uint32_t m, const u64 r[4],
-                 const u64 s_[4], const u64* w, uint8_t proof[256], u64* h_opt) {
+/* create_proof_with_reduction_and_matrices.  r, s Montgomery.  h_opt: if non-NULL receives h.
+ * reduction 0 = CircomReduction, 1 = LibsnarkReduction (H query of domain_size - 1 points; the
+ * caller's array may carry a padding entry, which msm_bigint's min(bases, scalars) never reads). */
+int g16cpu_prove_ex(const pkey_t* key, const csr_t* A, const csr_t* B, uint32_t m, const u64 r[4],
+                    const u64 s_[4], const u64* w, uint8_t proof[256], u64* h_opt, int reduction) {
   const uint32_t N = key->n_vars, p = key->n_public, ni = p + 1;
   uint32_t n = 0;
   u64* h = (u64*)malloc((size_t)key->domain_size * 32);
-  int st = g16cpu_witness_map(A, B, ni, m, w, h, &n);
+  int st = reduction == 1 ? g16cpu_witness_map_libsnark(A, B, ni, m, w, h, &n)
+                          : g16cpu_witness_map(A, B, ni, m, w, h, &n);
   if (st) { free(h); return st; }
   if (n != key->domain_size) { free(h); return 1; }
   if (h_opt) memcpy(h_opt, h, (size_t)n * 32);
+  if (reduction == 1) n -= 1;   /* h_query holds n - 1 points */
   u64 rc[4], sc[4], rs[4];
   fp_from_mont(rc, r, &FR); fp_from_mont(sc, s_, &FR);
   fp_mul(rs, r, s_, &FR); fp_from_mont(rs, rs, &FR);
@@ -459,6 +508,11 @@ int g16cpu_prove(const pkey_t* key, const csr_t* A, const csr_t* B, uint32_t m, 
   g1_to_aff(&pa, &g_a); g2_to_aff(&pb, &g2_b); g1_to_aff(&pc, &g_c);
   memcpy(proof, &pa, 64); memcpy(proof + 64, &pb, 128); memcpy(proof + 192, &pc, 64);
   return 0;
+}
+
+int g16cpu_prove(const pkey_t* key, const csr_t* A, const csr_t* B, uint32_t m, const u64 r[4],
+                 const u64 s_[4], const u64* w, uint8_t proof[256], u64* h_opt) {
+  return g16cpu_prove_ex(key, A, B, m, r, s_, w, proof, h_opt, 0);
 }
 
 /* k * P for tests (P affine bytes, k canonical) */

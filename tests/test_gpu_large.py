@@ -216,11 +216,13 @@ def test_dense_skewed_circuit_2p14_vs_cpu_restatement(gpulib, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("logm", [16])
-def test_libsnark_reduction_large_pairing(gpulib, logm):
-    """arkworks-style key (LibsnarkReduction, reference tests/groth16.rs path) at 2^16: multi-pass
-    coset NTTs + the 7th inverse transform; the proof verifies, a wrong public input is rejected,
-    and the key's H query really is Z(tau)/delta * tau^i (spot checks against the oracle)."""
+@pytest.mark.parametrize("logm", [16, 20])
+def test_libsnark_reduction_large_bytes_and_pairing(gpulib, logm):
+    """arkworks-style key (LibsnarkReduction, reference tests/groth16.rs:11-40 path) at 2^16 and 2^20:
+    multi-pass coset NTTs + the 7th inverse transform.  Proof BYTES == the C restatement's Libsnark
+    prove (pinned to the Python oracle at <= 2^10, tests/test_oracle.py), h element for element at
+    2^16; the proof verifies, a wrong public input is rejected, and the key's H query really is
+    Z(tau)/delta * tau^i (spot checks against the oracle)."""
     import circom_compat_amd as cc
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     import bench
@@ -236,7 +238,15 @@ def test_libsnark_reduction_large_pairing(gpulib, logm):
         assert bytes(pk.h_query[i]) == o.g1_to_bytes(o.G1.mul(o.G1_GEN, k))
     assert not pk.h_query[n - 1].any()                      # padding: the point at infinity
     r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
-    proof = cc.Prover(pk, mats, reduction="libsnark").prove(r, s, w_ints)
+    pr = cc.Prover(pk, mats, reduction="libsnark")
+    proof = pr.prove(r, s, w_ints)
+    import cpu_ref
+    rs = cc.fr_from_ints([r, s])
+    w = cc.fr_from_ints(w_ints)
+    want, h_c = cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w, want_h=True, reduction="libsnark")
+    assert proof.raw == want, "GPU Libsnark proof bytes differ from the C restatement at 2^%d" % logm
+    if logm <= 16:
+        assert np.array_equal(pr.witness_map(w), h_c)
     vk = dict(alpha_g1=o.g1_from_bytes(bytes(pk.vk.alpha_g1)), beta_g2=o.g2_from_bytes(bytes(pk.vk.beta_g2)),
               gamma_g2=o.g2_from_bytes(bytes(pk.vk.gamma_g2)), delta_g2=o.g2_from_bytes(bytes(pk.vk.delta_g2)),
               ic=[o.g1_from_bytes(bytes(x)) for x in pk.vk.gamma_abc_g1])

@@ -197,3 +197,51 @@ def test_c_oracle_matches_python_oracle(golden):
     assert got == o.proof_to_bytes(want)
     assert H.fr_from_mont_arr(h) == o.witness_map_from_matrices(ar, br, 2, len(cons), wit)
     assert o.verify_proof(opk, wit[1:2], want)
+
+
+@pytest.mark.parametrize("logm,kind", [(5, "chain"), (8, "chain"), (10, "chain"), (7, "dense")])
+def test_c_oracle_libsnark_reduction_matches_python_oracle(logm, kind):
+    """oracle/groth16_cpu.c's LibsnarkReduction witness map (coset g = 5, division by Z_H, inverse coset
+    transform) and the prove that uses it == oracle/bn254_ref.py's restatement at 2^5 .. 2^10 (chain
+    and uneven rows): the large-size Libsnark checker of tests/test_gpu_large.py stands on this pin;
+    the Python restatement is itself anchored by the pairing predicate (tests above)."""
+    import cpu_ref
+    if kind == "dense":
+        cons, wit, nv, _ = H.dense_skewed_circuit((1 << logm) - 5, seed=5, long_rows=(9,))
+        npub = 1
+    else:
+        cons, wit, nv, npub = H.squaring_chain(logm)
+    rng = random.Random(logm)
+    opk = o.trapdoor_setup(cons, nv, npub, *[rng.randrange(1, o.R_MOD) for _ in range(5)], reduction="libsnark")
+    ar, br = o.matrices_from_r1cs(cons)
+
+    class M:
+        pass
+
+    def csr(rows):
+        m = M()
+        m.row_ptr = np.array([0] + list(np.cumsum([len(r) for r in rows])), dtype=np.uint32)
+        m.col = np.array([i for r in rows for _c, i in r], dtype=np.uint32)
+        m.coeff = H.fr_mont_arr([c for r in rows for c, _i in r])
+        return m
+    mats = M()
+    mats.a, mats.b, mats.num_constraints = csr(ar), csr(br), len(cons)
+    ni = npub + 1
+    h_c = cpu_ref.witness_map(mats.a, mats.b, ni, len(cons), H.fr_mont_arr(wit), reduction="libsnark")
+    h_py = o.witness_map_libsnark(ar, br, ni, len(cons), wit)
+    assert H.fr_from_mont_arr(h_c) == h_py and h_py[-1] == 0
+    pk = M()
+    pk.n_vars, pk.n_public, pk.domain_size = nv, npub, opk["domain_size"]
+    pk.a_query, pk.b_g1_query, pk.b_g2_query = H.g1_arr(opk["a_query"]), H.g1_arr(opk["b_g1_query"]), H.g2_arr(opk["b_g2_query"])
+    pk.l_query, pk.h_query = H.g1_arr(opk["l_query"]), H.g1_arr(opk["h_query"])
+    assert len(opk["h_query"]) == opk["domain_size"] and opk["h_query"][-1] is None   # padded with infinity
+    pk.vk = M()
+    pk.vk.alpha_g1, pk.vk.beta_g2, pk.vk.delta_g2 = o.g1_to_bytes(opk["alpha_g1"]), o.g2_to_bytes(opk["beta_g2"]), o.g2_to_bytes(opk["delta_g2"])
+    pk.beta_g1, pk.delta_g1 = o.g1_to_bytes(opk["beta_g1"]), o.g1_to_bytes(opk["delta_g1"])
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    got = cpu_ref.prove(pk, mats, H.fr_mont_arr([r]), H.fr_mont_arr([s]), H.fr_mont_arr(wit), reduction="libsnark")
+    want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=ar, b=br), ni, len(cons), wit,
+                                                      reduction="libsnark")
+    assert got == o.proof_to_bytes(want)
+    if logm <= 8:
+        assert o.verify_proof(opk, wit[1:ni], want)
