@@ -30,6 +30,9 @@ witness map distributed (four-step NTTs, two all-to-all exchanges), records gath
 Other workloads / modes (BASELINE configs 2 and 5, the reference's own bench circuit):
   --workload dense-skewed   3-term A rows / 2-term B rows, >= 50 % of the witness in {0, 1}, key
                             written and re-read through the snarkjs .zkey format (read_zkey path)
+  --workload poseidon       the shape of a circom Poseidon hash chain: x^5 S-boxes as three rows, 4-term
+                            linear combinations with full-width MDS / round constants on both the A
+                            and the B side, uniform 254-bit witness; key through the .zkey format
   --workload complex-circuit  tests/golden/complex-circuit-10000-10000.r1cs (benches/groth16.rs:87-108)
   --mode parts              witness map and each MSM timed separately (device-resident operands)
 
@@ -134,6 +137,102 @@ def dense_skewed_circuit(cc, k, seed=5, n_bits=4096, n_wide=64, p_bit=0.64):
     A = cc.Csr(a_rp, a_col, cc.fr_from_ints(a_val))
     B = cc.Csr(b_rp, b_col, cc.fr_from_ints(b_val))
     Cm = cc.Csr(c_rp, c_col, np.tile(one, (len(c_col), 1)))
+    mats = cc.ConstraintMatrices(2, n_vars - 1, m, A, B)
+    return mats, (A, B, Cm), w, n_vars
+
+
+def poseidon_circuit(cc, k, seed=7, t=3, full_rounds=8, partial_rounds=57):
+    """BASELINE configs[4] substitute with the SHAPE of a circom Poseidon hash chain (the real artefact
+    needs circom + snarkjs + a ptau file: not generable offline): m = 2^k - 2 rows of chained width-3
+    permutations, 8 full + 57 partial rounds, x^5 S-box.  As circom emits it without the sparse-matrix
+    optimisation: the linear layer is folded into the consumer's linear combination, so an S-box is
+
+        (sum_j M[i][j] s_j + c_r,i) * (same) = x2      4-term A and 4-term B, FULL-WIDTH coefficients
+        x2 * x2 = x4
+        x4 * (sum_j M[i][j] s_j + c_r,i) = x5          4-term B
+
+    and a lane that skips the S-box in a partial round is materialised by a linear row
+    (sum_j M[i][j] s_j + c) * 1 = s'.  M is a Cauchy matrix 1 / (x_i + y_j) (the Poseidon
+    construction); the round constants are seeded uniform field elements, NOT the Grain-LFSR constants
+    of a real instance -- this is a benchmark shape, not a hash.  Each permutation absorbs one fresh
+    private input; every wire but the constant is a uniform 254-bit value (no 0/1 wires: the opposite
+    corner of the witness space from `dense-skewed`).  2.6 / 2.4 nnz per A / B row, most of them
+    full-width."""
+    R = R_MOD
+    rng = random.Random(seed)
+    m = (1 << k) - 2
+    rounds = full_rounds + partial_rounds
+    rc = [[rng.randrange(1, R) for _ in range(t)] for _ in range(rounds)]
+    xs = [rng.randrange(1, R) for _ in range(t)]
+    ys = [rng.randrange(1, R) for _ in range(t)]
+    M = [[pow((xs[i] + ys[j]) % R, R - 2, R) for j in range(t)] for i in range(t)]
+    table, tindex = [1], {1: 0}                       # distinct coefficient values -> converted once
+
+    def cid(v):
+        if v not in tindex:
+            tindex[v] = len(table)
+            table.append(v)
+        return tindex[v]
+
+    w = [1, 0] + [rng.randrange(R) for _ in range(t)]
+    state = list(range(2, 2 + t))
+    a_rp, b_rp, c_rp = [0], [0], [0]
+    a_col, a_cf, b_col, b_cf, c_col = [], [], [], [], []
+
+    def row(A, B, cw):
+        for j, c in A:
+            a_col.append(j)
+            a_cf.append(c)
+        for j, c in B:
+            b_col.append(j)
+            b_cf.append(c)
+        c_col.append(cw)
+        a_rp.append(len(a_col))
+        b_rp.append(len(b_col))
+        c_rp.append(len(c_col))
+
+    one = [(0, 0)]                                     # the constant wire with coefficient table[0] = 1
+    rows, r_idx = 0, 0
+    budget = m - 1
+    while rows < budget:
+        r = r_idx % rounds
+        if r == 0 and r_idx:                           # next permutation: chain lane 0 and 2, absorb a fresh input
+            w.append(rng.randrange(R))
+            state = [state[0], len(w) - 1, state[1]]
+        full = r < full_rounds // 2 or r >= rounds - full_rounds // 2
+        sv = [w[j] for j in state]
+        nxt = []
+        for i in range(t):
+            if rows >= budget:
+                nxt.append(state[i])
+                continue
+            lc = [(state[j], cid(M[i][j])) for j in range(t)] + [(0, cid(rc[r][i]))]
+            val = (sum(M[i][j] * sv[j] for j in range(t)) + rc[r][i]) % R
+            if (full or i == 0) and rows + 3 <= budget:
+                x2 = val * val % R
+                x4 = x2 * x2 % R
+                x5 = x4 * val % R
+                base = len(w)
+                w.extend((x2, x4, x5))
+                row(lc, lc, base)
+                row([(base, 0)], [(base, 0)], base + 1)
+                row([(base + 1, 0)], lc, base + 2)
+                rows += 3
+                nxt.append(base + 2)
+            else:
+                w.append(val)
+                row(lc, one, len(w) - 1)
+                rows += 1
+                nxt.append(len(w) - 1)
+        state = nxt
+        r_idx += 1
+    w[1] = w[state[0]]                                 # public output: lane 0 of the last state
+    row([(state[0], 0)], one, 1)
+    n_vars = len(w)
+    tab = cc.fr_from_ints(table)
+    A = cc.Csr(a_rp, a_col, tab[np.asarray(a_cf, dtype=np.int64)])
+    B = cc.Csr(b_rp, b_col, tab[np.asarray(b_cf, dtype=np.int64)])
+    Cm = cc.Csr(c_rp, c_col, np.tile(tab[0], (len(c_col), 1)))
     mats = cc.ConstraintMatrices(2, n_vars - 1, m, A, B)
     return mats, (A, B, Cm), w, n_vars
 
@@ -243,7 +342,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2", type=int, default=22, help="log2 of the domain (m = 2^k - 2 constraints)")
-    ap.add_argument("--workload", choices=["chain", "dense-skewed", "complex-circuit"], default="chain")
+    ap.add_argument("--workload", choices=["chain", "dense-skewed", "poseidon", "complex-circuit"], default="chain")
     ap.add_argument("--mode", choices=["prove", "parts"], default="prove")
     ap.add_argument("--cpu-log2", type=int, default=17, help="probe size of the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=60.0,
@@ -308,6 +407,11 @@ def main():
     elif args.workload == "dense-skewed":
         mats, (A, B, Cm), w_ints, n_vars = dense_skewed_circuit(cc, k)
         desc = (f"synthetic dense-rows R1CS (3-term A / 2-term B rows), 2^{k}-2 constraints, skewed witness, "
+                "key through the snarkjs .zkey writer + read_zkey")
+    elif args.workload == "poseidon":
+        mats, (A, B, Cm), w_ints, n_vars = poseidon_circuit(cc, k)
+        desc = (f"Poseidon-shaped hash-chain R1CS (width 3, 8 + 57 rounds, x^5 as 3 rows, 4-term linear "
+                f"combinations with full-width MDS / round constants, uniform witness), 2^{k}-2 constraints, "
                 "key through the snarkjs .zkey writer + read_zkey")
     else:
         mats, (A, B, Cm), w_ints, n_vars = complex_circuit(cc)

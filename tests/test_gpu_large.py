@@ -485,6 +485,68 @@ def test_dense_skewed_2p20_through_zkey_vs_cpu_restatement(gpulib, tmp_path):
     assert o.verify_proof(_vk_dict(pk), [w_ints[1]], H.proof_from_bytes(proof.raw))
 
 
+def _through_zkey(cc, tmp_path, name, A, B, Cm, n_vars, mats0, seed):
+    rng = random.Random(seed)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    pk0 = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox)
+    path = str(tmp_path / name)
+    cc.write_zkey(path, pk0, mats0)
+    pk, mats = cc.read_zkey(path)
+    return pk, mats, rng
+
+
+def test_poseidon_shaped_2p20_through_zkey_vs_cpu_restatement(gpulib, tmp_path):
+    """BASELINE configs[4] substitute with the shape of a circom Poseidon hash chain AT SIZE (2^20 rows:
+    x^5 S-boxes as three rows, 4-term linear combinations with full-width MDS / round constants in A
+    AND B, uniform 254-bit witness -- bench.poseidon_circuit): satisfiable (GPU constraint check), key
+    through g16_zkey_write -> read_zkey (the Coefs path, src/zkey.rs:151-196, with full-width values),
+    proof bytes == the CPU restatement's, pairing accepted, wrong public input rejected."""
+    import circom_compat_amd as cc
+    import cpu_ref
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    k = 20
+    mats0, (A, B, Cm), w_ints, n_vars = bench.poseidon_circuit(cc, k)
+    assert sum(1 for x in w_ints if x in (0, 1)) <= 4           # uniform witness
+    wide = sum(1 for x in cc.fr_to_ints(A.coeff[:20000]) if x.bit_length() > 200)
+    assert wide > 10000                                          # full-width coefficients dominate
+    circ = cc.CircomCircuit(type("R", (), dict(a=A, b=B, c=Cm, num_constraints=mats0.num_constraints,
+                                               wire_mapping=None, num_inputs=2, num_variables=n_vars)), w_ints)
+    assert circ.first_unsatisfied() == -1
+    pk, mats, rng = _through_zkey(cc, tmp_path, "poseidon20.zkey", A, B, Cm, n_vars, mats0, k)
+    rs = cc.fr_from_ints([rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)])
+    w = cc.fr_from_ints(w_ints)
+    proof = cc.Prover(pk, mats).prove(rs[0], rs[1], w)
+    assert proof.raw == cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
+    assert o.verify_proof(_vk_dict(pk), [w_ints[1]], H.proof_from_bytes(proof.raw))
+    assert not o.verify_proof(_vk_dict(pk), [(w_ints[1] + 1) % o.R_MOD], H.proof_from_bytes(proof.raw))
+
+
+@pytest.mark.parametrize("shard", ["points", "buckets"])
+@pytest.mark.parametrize("workload", ["dense-skewed", "poseidon"])
+def test_config5_substitutes_sharded_over_8_ranks_2p17(gpulib, tmp_path, workload, shard):
+    """The two config-5 substitutes through g16_ctx_create_multi([0] * 8) at 2^17 rows, both ways of
+    cutting the MSMs: `dense-skewed` puts ~45 % of all sort entries into ONE bucket (the value-1 wires)
+    -- split over point-range shards it spans many lanes of every rank, under bucket ranges it makes
+    one partition larger than a rank's fair share (that rank owns it alone); `poseidon` is the
+    uniform full-width corner.  bytes == the CPU restatement's, two proofs."""
+    import circom_compat_amd as cc
+    import cpu_ref
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    k = 17
+    gen = bench.dense_skewed_circuit if workload == "dense-skewed" else bench.poseidon_circuit
+    mats0, (A, B, Cm), w_ints, n_vars = gen(cc, k)
+    pk, mats, rng = _through_zkey(cc, tmp_path, workload + "17.zkey", A, B, Cm, n_vars, mats0, k)
+    w = cc.fr_from_ints(w_ints)
+    pr = cc.Prover(pk, mats, devices=[0] * 8, shard=shard)
+    assert pr.info()["shard_mode"] == shard
+    for _ in range(2):
+        rs = cc.fr_from_ints([rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)])
+        assert pr.prove(rs[0], rs[1], w).raw == cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
+    pr.close()
+
+
 RCCL_WORKER = r'''
 import os, sys, random
 import numpy as np

@@ -639,3 +639,39 @@ def test_bucket_range_sharding_windows_planes_and_skew(lib, logm, world, wb, pla
         want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), n_pub + 1, len(cons), w)
         assert pr.prove(r, s, w).raw == o.proof_to_bytes(want)
     pr.close()
+
+
+def test_poseidon_shaped_generator_full_width_rows_vs_oracle(lib):
+    """bench.poseidon_circuit (the config-5 substitute with full-width coefficients on both sides of
+    the product rows) at 2^7 rows: satisfiable, and the proof over a trapdoor key == the Python oracle's
+    -- on one device and on 4 bucket-sharded ranks."""
+    import sys
+    import circom_compat_amd as cc
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from circom_compat_amd import _binding
+    saved, _binding._default = _binding._default, lib       # the generator converts through the default library
+    try:
+        mats, (A, B, Cm), w, n_vars = bench.poseidon_circuit(cc, 7)
+    finally:
+        _binding._default = saved
+    circ = cc.CircomCircuit(type("R", (), dict(a=A, b=B, c=Cm, num_constraints=mats.num_constraints,
+                                               wire_mapping=None, num_inputs=2, num_variables=n_vars)), w)
+    assert circ.first_unsatisfied(lib) == -1
+
+    def rows(m):
+        cf = cc.fr_to_ints(m.coeff, lib)
+        return [[(int(m.col[j]), cf[j]) for j in range(m.row_ptr[i], m.row_ptr[i + 1])] for i in range(m.num_rows)]
+    cons = list(zip(rows(A), rows(B), rows(Cm)))
+    assert max(len(a) for a, _b, _c in cons) == 4 and max(len(b) for _a, b, _c in cons) == 4
+    rng = random.Random(77)
+    opk = o.trapdoor_setup(cons, n_vars, 1, *[rng.randrange(1, o.R_MOD) for _ in range(5)])
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    want = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2,
+                                                                       len(cons), w))
+    pk = H.pk_from_oracle(opk)
+    assert cc.Prover(pk, mats, lib=lib).prove(r, s, w).raw == want
+    pr = cc.Prover(pk, mats, lib=lib, devices=[0] * 4, shard="buckets")
+    assert pr.prove(r, s, w).raw == want
+    pr.close()
