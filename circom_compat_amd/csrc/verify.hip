@@ -181,6 +181,7 @@ G16_NOINLINE void line(F12* l_out, G2Affine* T, const G2Affine* Qp, const G1Affi
   for (int i = 0; i < 12; ++i) l.c[i] = Fq::zero();
   if (*t_inf) {  // T at infinity (degenerate inputs only): the line is 1, T + Q = Q
     *l_out = f12_one();
+    if (Qp == T) return;  // doubling step: 2 * infinity = infinity
     *T = *Qp;
     *t_inf = false;
     return;
@@ -250,6 +251,25 @@ G16_HD bool on_curve_g2(const G2Affine& p, const VkDev* vk) {
   return p.y.sqr() == p.x.sqr() * p.x + vk->b_twist;
 }
 
+// coordinate as stored (8 words) is a canonical residue, i.e. < q: what ark-serialize enforces when
+// it deserialises a Proof (a value >= q would be a second encoding of the same element)
+G16_HD bool fq_words_canonical(const Fq& a) {
+  for (int i = 7; i >= 0; --i) {
+    if (a.v[i] < FqParams::MOD[i]) return true;
+    if (a.v[i] > FqParams::MOD[i]) return false;
+  }
+  return false;  // == q
+}
+// B in the r-torsion of the twist: [r] B = infinity.  The twist E'(Fq2) has a large cofactor
+// (2q - r), so an on-curve B need not be in G2; ark-ec's G2Affine deserialisation performs this
+// check before the reference ever pairs a point.  ~380 Fq2 point operations, ~10 % of one pairing check.
+G16_HD bool g2_in_subgroup(const G2Affine& p) {
+  if (p.is_inf()) return true;
+  U256 r;
+  for (int i = 0; i < 8; ++i) r.v[i] = FrParams::MOD[i];
+  return XYZZ<Fq2>::from_affine(p).mul(r).is_inf();
+}
+
 namespace {
 
 __global__ void k_verify_prepare(VkDev* vk) {
@@ -270,7 +290,13 @@ __global__ void __launch_bounds__(64) k_verify_batch(const VkDev* vk, const G1Af
   memcpy(&A, proofs + (size_t)i * G16_PROOF_BYTES, 64);
   memcpy(&B, proofs + (size_t)i * G16_PROOF_BYTES + 64, 128);
   memcpy(&C, proofs + (size_t)i * G16_PROOF_BYTES + 192, 64);
-  if (!(on_curve_g1(A) && on_curve_g1(C) && on_curve_g2(B, vk))) {
+  // what deserialising a Proof enforces in the reference (ark-serialize, Validate::Yes) before any
+  // pairing runs: canonical coordinates, points on their curves, B in the prime-order subgroup
+  // (G1 has cofactor 1).  Anything else is rejected here, never paired.
+  const bool canonical = fq_words_canonical(A.x) && fq_words_canonical(A.y) && fq_words_canonical(C.x) &&
+                         fq_words_canonical(C.y) && fq_words_canonical(B.x.c0) && fq_words_canonical(B.x.c1) &&
+                         fq_words_canonical(B.y.c0) && fq_words_canonical(B.y.c1);
+  if (!(canonical && on_curve_g1(A) && on_curve_g1(C) && on_curve_g2(B, vk) && g2_in_subgroup(B))) {
     ok[i] = 0;
     return;
   }

@@ -259,7 +259,10 @@ typedef struct {
  * tests/groth16.rs:33-35) for n_proofs proofs under one key, one GPU lane per proof:
  *   ok_out[i] = 1 iff e(A_i, B_i) = e(alpha, beta) e(IC_0 + sum_j pub_ij IC_{j+1}, gamma) e(C_i, delta)
  * proofs: n_proofs x G16_PROOF_BYTES (A | B | C as g16_prove writes them); public_inputs:
- * n_proofs x (ic_count - 1) x 4 u64 Montgomery Fr.  Points off their curve give 0.                */
+ * n_proofs x (ic_count - 1) x 4 u64 Montgomery Fr.  The reference only ever pairs a DESERIALISED
+ * Proof, and ark-serialize (Validate::Yes) rejects what this call therefore rejects itself with
+ * ok = 0 before any pairing: a coordinate that is not canonical (stored value >= q), a point off its
+ * curve, a B outside the prime-order subgroup of the twist ([r] B != infinity).                     */
 g16_status g16_verify_batch(int device, const g16_vk_desc* vk, const uint8_t* proofs,
                             const uint64_t* public_inputs, uint32_t n_proofs, uint8_t* ok_out);
 

@@ -80,3 +80,60 @@ def test_verify_batch_public_input_counts(lib, n_pub):
         pubs.append(bad)
     assert cc.verify_batch(vk, batch, pubs, lib=lib) == [True] + [False] * n_pub
     assert o.verify_proof(opk, pub, H.proof_from_bytes(proof.raw))
+
+
+def _twist_point_outside_g2(seed):
+    """a point of E'(Fq2): y^2 = x^3 + 3/(9+i) that is NOT in the r-torsion (the twist's cofactor is
+    2q - r: a random point is outside G2 with overwhelming probability; checked with [r]P != inf)"""
+    q = o.Q_MOD
+    rng = random.Random(seed)
+
+    def fq_sqrt(a):
+        s = pow(a, (q + 1) // 4, q)
+        return s if s * s % q == a % q else None
+
+    while True:
+        x = (rng.randrange(q), rng.randrange(q))
+        rhs = o.f2_add(o.f2_mul(o.f2_sqr(x), x), o.G2_B)
+        a0, a1 = rhs
+        n = fq_sqrt((a0 * a0 + a1 * a1) % q)                   # sqrt of the norm
+        if n is None:
+            continue
+        for sgn in (n, q - n):
+            half = (a0 + sgn) * pow(2, q - 2, q) % q
+            y0 = fq_sqrt(half)
+            if y0 is None or y0 == 0:
+                continue
+            y = (y0, a1 * pow(2 * y0, q - 2, q) % q)
+            if o.f2_sqr(y) == (rhs[0] % q, rhs[1] % q):
+                P = (x, y)
+                if o.G2.mul(P, o.R_MOD) is not None:
+                    return P
+
+
+def test_verify_batch_rejects_what_deserialisation_rejects(lib, golden):
+    """ark-groth16 only ever pairs a deserialised Proof, and that deserialisation (Validate::Yes)
+    rejects (i) a B that is on the twist but outside the prime-order subgroup and (ii) coordinates
+    that are not canonical (>= q: a second encoding of the same point, i.e. a malleable proof).
+    g16_verify_batch takes raw bytes, so it must refuse both itself -- a valid proof beside them
+    still verifies."""
+    import circom_compat_amd as cc
+    data = open(os.path.join(golden, "test.zkey"), "rb").read()
+    opk, omats = o.read_zkey(data)
+    vk = _vk(cc, opk)
+    good = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, 5, 7, omats, 2, 1, [1, 33, 3, 11]))
+    T = _twist_point_outside_g2(1)
+    assert o.G2.mul(T, o.R_MOD) is not None
+    cof = good[:64] + o.g2_to_bytes(T) + good[192:]                      # on the curve, wrong subgroup
+    B = H.proof_from_bytes(good)["b"]
+    mixed = good[:64] + o.g2_to_bytes(o.G2.add(B, o.G2.mul(T, o.R_MOD))) + good[192:]   # B + a cofactor-torsion point
+    assert o.G2.mul(o.G2.mul(T, o.R_MOD), 2 * o.Q_MOD - o.R_MOD) is None  # [r]T has order dividing the cofactor
+
+    def plus_q(raw, off):                                                # stored value m -> m + q (< 2^256)
+        v = int.from_bytes(raw[off:off + 32], "little") + o.Q_MOD
+        assert v < 1 << 256
+        return raw[:off] + v.to_bytes(32, "little") + raw[off + 32:]
+    noncanon = [plus_q(good, off) for off in (0, 32, 64, 160, 192, 224)]  # A.x, A.y, B.x.c0, B.y.c1, C.x, C.y
+    batch = [good, cof, mixed] + noncanon + [good]
+    got = cc.verify_batch(vk, batch, [[33]] * len(batch), lib=lib)
+    assert got == [True, False, False] + [False] * len(noncanon) + [True]
