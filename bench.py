@@ -14,9 +14,9 @@ section 8(d) with m = 2^22 - 2 constraints, a real trapdoor key minted on the GP
 The SURVEY 8(d) step (host witness -> H2D -> ... -> 256 B D2H, witness in the ctx's page-locked
 staging buffer) is timed right after it and reported as `value_pcie_inclusive`.
 
-N > 1 (strong scaling of ONE proof): MSMs sharded by bucket range (--shard buckets / auto: every GPU
-holds the whole key and the single-GPU window, keeps 1/N of the sorted bucket list; the only MSM
-traffic is the all-gather of h and a 1 KiB record per rank) or by point range (--shard points),
+N > 1 (strong scaling of ONE proof): witness-scalar MSMs sharded by bucket range (--shard buckets /
+auto: every GPU holds all A/B1/B2/L points and the single-GPU window, keeps 1/N of the sorted bucket
+list; the only MSM traffic is a 1 KiB record per rank) or by point range (--shard points; H always),
 witness map distributed (four-step NTTs, two all-to-all exchanges), records gathered and summed.
   mode "in-library"  (default when this process can see N devices): rank 0 drives all N GPUs through
                      ONE g16_ctx_create_multi ctx -- exchanges are peer copies over xGMI inside the
@@ -477,42 +477,6 @@ def main():
             recv = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         part_t = cc.device_tensor(prover.partial_buffer(), 1024, dev)
         gath_t = cc.device_tensor(prover.gather_buffer(), world * 1024, dev)
-        by_buckets = prover.info()["shard_mode"] == "buckets"
-        if dist_wm and by_buckets:
-            hb = prover.h_bytes()
-            h_all = cc.device_tensor(prover.h_gather_buffer(), world * hb, dev)
-            h_mine = h_all[rank * hb:(rank + 1) * hb]      # in place: sendbuff = recvbuff + rank * count
-
-        def gather_h():
-            with torch.cuda.stream(xs):
-                if backend == "nccl":
-                    dist.all_gather_into_tensor(h_all, h_mine, group=grp)
-                else:
-                    xs.synchronize()
-                    hs = [torch.empty(hb, dtype=torch.uint8) for _ in range(world)]
-                    dist.all_gather(hs, h_mine.cpu())
-                    h_all.copy_(torch.cat(hs))
-
-        def exchange():
-            with torch.cuda.stream(xs):
-                if backend == "nccl":
-                    dist.all_to_all_single(recv, send, group=grp)
-                else:
-                    xs.synchronize()
-                    hs, hr = send.cpu(), torch.empty(nbytes, dtype=torch.uint8)
-                    dist.all_to_all_single(hr, hs)
-                    recv.copy_(hr)
-
-        def gather():
-            with torch.cuda.stream(xs):
-                if backend == "nccl":
-                    dist.all_gather_into_tensor(gath_t, part_t, group=grp)
-                else:
-                    xs.synchronize()
-                    parts = [torch.empty(1024, dtype=torch.uint8) for _ in range(world)]
-                    dist.all_gather(parts, part_t.cpu())
-                    gath_t.copy_(torch.cat(parts))
-
     def step():
         if mode in ("single", "inlib"):
             return prover.prove_dev(rs[0], rs[1], w_ptr)
@@ -521,12 +485,7 @@ def main():
             exchange()
             prover.dist_phase2(recv.data_ptr(), send.data_ptr())
             exchange()
-            if by_buckets:
-                prover.dist_phase3h(recv.data_ptr())       # this rank's h scalars, in its slice of h_all
-                gather_h()
-                prover.dist_phase4_dev()
-            else:
-                prover.dist_phase3_dev(recv.data_ptr())
+            prover.dist_phase3_dev(recv.data_ptr())
         else:
             raise SystemExit("mode 'ranks' runs the fully sharded prover (G16_BENCH_DIST_WM=1)")
         gather()
@@ -735,7 +694,7 @@ def main():
     if mode == "single":
         par = "single-gpu"
     else:
-        cut = ("msm-bucket-range-shard (whole key on every GPU, 1/N of the sorted bucket list per rank, h all-gather)"
+        cut = ("msm-bucket-range-shard (A/B1/B2/L points on every GPU, 1/N of the sorted bucket list per rank; H by point range)"
                if info.get("shard_mode") == "buckets" else "msm-point-range-shard")
         par = (f"{cut} x{n_gpus} + four-step witness map (2 all-to-all), "
                + ("one g16_ctx_create_multi ctx in one process: peer copies over xGMI inside the library"

@@ -397,7 +397,8 @@ class Prover:
         """devices=[d0, d1, ...]: ONE ctx sharded over several GPUs inside the library
         (g16_ctx_create_multi); prove() / prove_dev() are then used exactly as on one device.
         shard (world > 1 / devices): "points" = point-range MSM shards, "buckets" = every rank holds
-        the whole key and 1/world of the sorted bucket list, "auto" = buckets when the key fits."""
+        all points of the witness queries and 1/world of their sorted bucket list (H stays cut by
+        point range), "auto" = buckets when the key fits."""
         self.lib = lib or B.load()
         self.matrices = matrices
         self.pk = pk
@@ -530,28 +531,6 @@ class Prover:
         self.lib.check(self.lib.g16_prove_dist_phase3(self.ctx, C.c_void_p(recv_ptr), _np_ptr(out)),
                        self.ctx)
         return out.tobytes()
-
-    # -- bucket-sharded ranks: phase 3 leaves the rank's h scalars, phase 4 follows their all-gather
-    def h_bytes(self) -> int:
-        return int(self.lib.g16_dist_h_bytes(self.ctx))
-
-    def h_gather_buffer(self) -> int:
-        return int(self.lib.g16_h_gather_buffer(self.ctx) or 0)
-
-    def dist_phase3h(self, recv_ptr: int, h_send_ptr: Optional[int] = None):
-        self.lib.check(self.lib.g16_prove_dist_phase3h(self.ctx, C.c_void_p(recv_ptr),
-                                                       C.c_void_p(h_send_ptr) if h_send_ptr else None), self.ctx)
-
-    def dist_phase4(self, h_all_ptr: Optional[int] = None) -> bytes:
-        out = np.empty(B.G16_PARTIAL_BYTES, dtype=np.uint8)
-        self.lib.check(self.lib.g16_prove_dist_phase4(self.ctx, C.c_void_p(h_all_ptr) if h_all_ptr else None,
-                                                      _np_ptr(out)), self.ctx)
-        return out.tobytes()
-
-    def dist_phase4_dev(self, h_all_ptr: Optional[int] = None):
-        """phase 4 with the record left in partial_buffer() (needs set_exchange_stream)"""
-        self.lib.check(self.lib.g16_prove_dist_phase4(self.ctx, C.c_void_p(h_all_ptr) if h_all_ptr else None,
-                                                      None), self.ctx)
 
     def prove_finish(self, r, s, partials: bytes) -> Proof:
         rs = _as_fr([r, s], self.lib) if not isinstance(r, np.ndarray) else np.stack([r, s])

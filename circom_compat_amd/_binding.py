@@ -94,8 +94,7 @@ ABI_SYMBOLS = [
     "g16_ctx_create", "g16_ctx_destroy", "g16_last_error", "g16_witness_map", "g16_msm_g1",
     "g16_msm_g2", "g16_prove", "g16_prove_dev", "g16_prove_partial", "g16_prove_partial_dev",
     "g16_prove_finish", "g16_dist_exchange_bytes", "g16_prove_dist_phase1", "g16_prove_dist_phase2",
-    "g16_prove_dist_phase3", "g16_dist_h_bytes", "g16_h_gather_buffer", "g16_prove_dist_phase3h",
-    "g16_prove_dist_phase4", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info",
+    "g16_prove_dist_phase3", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info",
     "g16_witness_buffer", "g16_witness_upload", "g16_witness_host_buffer", "g16_ctx_create_multi", "g16_dist_set_exchange_stream",
     "g16_partial_buffer", "g16_gather_buffer", "g16_prove_finish_dev", "g16_witness_map_dev", "g16_msm_g1_dev",
     "g16_msm_g2_dev", "g16_verify_batch", "g16_debug_ntt", "g16_debug_alu_bench", "g16_check_satisfied", "g16_zkey_write",
@@ -147,10 +146,6 @@ class Library:
             "g16_prove_dist_phase1": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp]),
             "g16_prove_dist_phase2": (C.c_int, [vp, vp, vp]),
             "g16_prove_dist_phase3": (C.c_int, [vp, vp, vp]),
-            "g16_dist_h_bytes": (C.c_size_t, [vp]),
-            "g16_h_gather_buffer": (vp, [vp]),
-            "g16_prove_dist_phase3h": (C.c_int, [vp, vp, vp]),
-            "g16_prove_dist_phase4": (C.c_int, [vp, vp, vp]),
             "g16_set_profiling": (C.c_int, [vp, C.c_int]),
             "g16_stage_times": (C.c_int, [vp, C.POINTER(C.c_float), _u32p]),
             "g16_stage_name": (C.c_char_p, [C.c_int]),

@@ -101,7 +101,9 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
   const uint32_t b2_limit = c->world > 1 ? (1u << 18) : (1u << 16);
   const bool b2_off = c->overlap && (knob_b2 < 0 ? nb_eff < b2_limit : knob_b2 != 0);
   static const int knob_off = [] { const char* e = getenv("G16_REDUCE_OFF_MAIN"); return e ? atoi(e) : -1; }();
-  const bool mid = nb_eff >= (1u << 15) && small;
+  // bucket-sharded ranks: a reduction only occupies 1/world of the chip's wave slots, so it always
+  // leaves the main stream, whatever the size of the shared bucket set
+  const bool mid = (nb_eff >= (1u << 15) && small) || (c->shard_buckets && c->world > 1 && nb_eff >= (1u << 15));
   if ((knob_off < 0 ? mid : knob_off != 0) && c->overlap && c->work1.batch >= 3) {
     // Mid-sized bucket sets (2^15..2^17: 2^18..2^20-constraint proofs, ranks of a sharded 2^22
     // one): every reduction is a latency-bound chain long enough to matter and short enough to
@@ -298,31 +300,9 @@ void rank_phase2_enqueue(g16_ctx* c, const int32_t* recv_dev, int32_t* send_dev)
 
 void rank_phase3_enqueue(g16_ctx* c, const int32_t* recv_dev) {
   G16_HIP(hipSetDevice(c->device));
-  if (c->shard_buckets) throw std::runtime_error("bucket-range sharding: phase 3 is followed by the all-gather of h and phase 4");
   hipStream_t s = c->stream, x = c->aux;
   c->wd.phase3(recv_dev, c->h_canon.p, x);
   c->sort_h.run(c->h_canon.p, c->h_hi - c->h_lo, /*mont=*/false, x);
-  G16_HIP(hipEventRecord(c->ev_h, x));
-  enqueue_h_msm(c);
-  G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));
-  sums_to_partial(c->sums_dev.p, c->part_dev(), s);
-  G16_HIP(hipEventRecord(c->ev_part, s));
-}
-
-void rank_phase3h_enqueue(g16_ctx* c, const int32_t* recv_dev, U256* h_out) {
-  G16_HIP(hipSetDevice(c->device));
-  const uint32_t per = c->n / (uint32_t)c->world;
-  c->wd.phase3(recv_dev, h_out ? h_out : c->h_canon.p + (size_t)c->rank * per, c->aux);
-  G16_HIP(hipEventRecord(c->ev_send, c->aux));
-}
-
-void rank_phase4_enqueue(g16_ctx* c, const U256* h_all) {
-  G16_HIP(hipSetDevice(c->device));
-  hipStream_t s = c->stream, x = c->aux;
-  StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
-  int id = tm ? tm->begin(ST_MSM_SORT, x) : -1;
-  c->sort_h.run(h_all ? h_all : c->h_canon.p, c->n, /*mont=*/false, x);
-  if (tm) tm->end(id, x);
   G16_HIP(hipEventRecord(c->ev_h, x));
   enqueue_h_msm(c);
   G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));
@@ -371,7 +351,8 @@ bool bucket_shard_fits(int device, uint32_t n_vars, uint32_t domain, const g16_o
   const size_t len_w = n_vars > 1 ? n_vars - 1 : 1;
   const MsmConfig cw = msm_make_config(len_w, opt ? opt->window_bits : 0, opt ? opt->planes : 0);
   const MsmConfig ch = msm_make_config(domain ? domain : 1, opt ? opt->window_bits : 0, opt ? opt->planes : 0);
-  // planes + both sorts (8 + 4 bytes per entry) + work buffers, against 70 % of what is free beyond 3 GiB
+  // planes (the H query stays point-sharded: counted whole, as an upper bound) + both sorts (8 + 4
+  // bytes per entry) + work buffers, against 70 % of what is free beyond 3 GiB
   const size_t planes = (size_t)cw.Pn * len_w * (64 * 3 + 128) + (size_t)ch.Pn * domain * 64;
   const size_t sorts = ((size_t)cw.W * len_w + (size_t)ch.W * domain) * 12;
   const size_t work = ((size_t)cw.nb() + cw.lanes) * (144 * 3 + 288) + ((size_t)ch.nb() + ch.lanes) * 144;
@@ -489,18 +470,19 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
                        (o.shard == G16_SHARD_BUCKETS ||
                         (o.shard == G16_SHARD_AUTO && (share_from || bucket_shard_fits(c->device, c->N, c->n, &o))));
     c->share_from = c->shard_buckets ? share_from : nullptr;
-    if (c->shard_buckets) {  // every rank holds every point; the sorts keep 1/world of the entries
+    // the H query is ALWAYS cut by point range: its scalars are born sharded (the distributed
+    // witness map leaves rank g the n / world evaluations e = global_index(t)), so every rank
+    // multiplies its own slice; only the witness-scalar queries (A, B1, B2, L: the witness is
+    // resident everywhere anyway) are cut by bucket range under G16_SHARD_BUCKETS
+    shard(len_w, c->rank, c->world, &c->w_lo, &c->w_hi);
+    shard(c->n, c->rank, c->world, &c->h_lo, &c->h_hi);
+    if (c->dist_wm) {  // the distributed witness map leaves n / world scalars, local order
+      c->h_lo = 0;
+      c->h_hi = c->n / (uint32_t)c->world;
+    }
+    if (c->shard_buckets) {  // every rank holds every witness-query point; the sort keeps 1/world of the entries
       c->w_lo = 0;
       c->w_hi = len_w;
-      c->h_lo = 0;
-      c->h_hi = c->n;
-    } else {
-      shard(len_w, c->rank, c->world, &c->w_lo, &c->w_hi);
-      shard(c->n, c->rank, c->world, &c->h_lo, &c->h_hi);
-      if (c->dist_wm) {  // the distributed witness map leaves n / world scalars, local order
-        c->h_lo = 0;
-        c->h_hi = c->n / (uint32_t)c->world;
-      }
     }
     const uint32_t lw = c->w_hi - c->w_lo, lh = c->h_hi - c->h_lo;
     const uint32_t wr = c->shard_buckets ? (uint32_t)c->world : 1u;  // ranks sharing one bucket set
@@ -549,7 +531,6 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       borrow(c->ptsB1, lender->ptsB1);
       borrow(c->ptsB2, lender->ptsB2);
       borrow(c->ptsL, lender->ptsL);
-      borrow(c->ptsH, lender->ptsH);
       c->l_idx_min = lender->l_idx_min;
     } else {
       if (no_pair) {
@@ -566,24 +547,16 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       c->l_idx_min = first - c->w_lo;
       c->ptsL.init((const G1Affine*)key->l_query + (first - c->p), cnt, c->cfg_w, s);
     }
-    c->cfg_h = lender ? lender->cfg_h : fit_config(lh ? lh : 1, o.window_bits, o.planes, 64, reserve);
+    c->cfg_h = fit_config(lh ? lh : 1, o.window_bits, o.planes, 64, reserve);
     c->sort_h.init(lh, c->cfg_h);
-    c->sort_h.set_shard(c->shard_buckets ? c->rank : 0, (int)wr);
-    if (lender) {
-      // planes borrowed above
-    } else if (c->dist_wm) {
-      // point-range shards: this rank's h scalars are the evaluations e = global_index(t) -- gather
-      // the matching points.  Bucket-range shards: all n scalars arrive rank after rank (the
-      // all-gather of the phase-3 outputs), so the whole H query is stored in that order.
+    if (c->dist_wm) {
+      // this rank's h scalars are the evaluations e = global_index(t): gather the matching points
       std::vector<G1Affine> mine(lh);
       const G1Affine* hq = (const G1Affine*)key->h_query;
-      const uint32_t per = c->n / (uint32_t)c->world;
       // byte copies: the caller's arrays carry no alignment (zero-copy views of zkey sections start
       // at arbitrary file offsets) and G1Affine is an over-aligned type
-      for (uint32_t t = 0; t < lh; ++t) {
-        const uint32_t e = c->shard_buckets ? c->wd.global_index_of((int)(t / per), t % per) : c->wd.global_index(t);
-        memcpy((void*)&mine[t], (const uint8_t*)hq + (size_t)e * sizeof(G1Affine), sizeof(G1Affine));
-      }
+      for (uint32_t t = 0; t < lh; ++t)
+        memcpy((void*)&mine[t], (const uint8_t*)hq + (size_t)c->wd.global_index(t) * sizeof(G1Affine), sizeof(G1Affine));
       c->ptsH.init(mine.data(), lh, c->cfg_h, s);
       G16_HIP(hipStreamSynchronize(s));  // `mine` is read by the async upload
     } else {
@@ -594,9 +567,9 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     // sort, G2 over the witness sort
     {
       const uint32_t nc_w = ceil_div(c->cfg_w.B, msm_red_chunk(c->cfg_w, 1, wr)) * c->cfg_w.D;
-      const uint32_t nc_h = ceil_div(c->cfg_h.B, msm_red_chunk(c->cfg_h, 1, wr)) * c->cfg_h.D;
+      const uint32_t nc_h = ceil_div(c->cfg_h.B, msm_red_chunk(c->cfg_h)) * c->cfg_h.D;
       const uint32_t slots_w = c->cfg_w.nb() + c->cfg_w.lanes, slots_h = c->cfg_h.nb() + c->cfg_h.lanes;
-      c->work1.init(slots_w, nc_w, c->cfg_w.D, /*batch=*/(c->cfg_w.nb() / wr < (1u << 18) || getenv("G16_BATCH_REDUCE")) ? 3 : 2);
+      c->work1.init(slots_w, nc_w, c->cfg_w.D, /*batch=*/(c->cfg_w.nb() / wr < (1u << 18) || wr > 1 || getenv("G16_BATCH_REDUCE")) ? 3 : 2);
       c->workH.init(slots_h, nc_h, c->cfg_h.D, 1);
       c->work2.init(slots_w, nc_w, c->cfg_w.D);
     }
@@ -952,49 +925,6 @@ g16_status g16_prove_dist_phase3(g16_ctx* c, const void* recv_dev,
     } else {
       // device-side hand-off: the record stays in g16_partial_buffer(); the caller's all-gather
       // (enqueued on the exchange stream) waits for it
-      G16_HIP(hipStreamWaitEvent(c->xstream, c->ev_part, 0));
-    }
-    return G16_OK;
-  });
-}
-
-size_t g16_dist_h_bytes(const g16_ctx* c) {
-  return (c && c->dist_wm && c->shard_buckets) ? (size_t)(c->n / (uint32_t)c->world) * 32 : 0;
-}
-void* g16_h_gather_buffer(g16_ctx* c) {
-  return (c && !c->multi && c->has_key && c->shard_buckets) ? (void*)c->h_canon.p : nullptr;
-}
-
-g16_status g16_prove_dist_phase3h(g16_ctx* c, const void* recv_dev, void* h_send_dev) {
-  if (!c || !recv_dev) return fail(c, G16_ERR_INVALID, "null argument");
-  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx: use g16_prove");
-  if (!c->dist_wm || !c->has_key || !c->shard_buckets)
-    return fail(c, G16_ERR_INVALID, "not a bucket-sharded dist_wm proving ctx");
-  return guarded(c, [&]() -> g16_status {
-    handback(c, c->aux);
-    rank_phase3h_enqueue(c, (const int32_t*)recv_dev, (U256*)h_send_dev);
-    handoff(c, c->ev_send, c->aux);  // this rank's h scalars are complete
-    return G16_OK;
-  });
-}
-
-g16_status g16_prove_dist_phase4(g16_ctx* c, const void* h_all_dev,
-                                 uint8_t partial_out[G16_PARTIAL_BYTES]) {
-  if (!c) return fail(c, G16_ERR_INVALID, "null argument");
-  if (c->multi) return fail(c, G16_ERR_INVALID, "multi-device ctx: use g16_prove");
-  if (!c->dist_wm || !c->has_key || !c->shard_buckets)
-    return fail(c, G16_ERR_INVALID, "not a bucket-sharded dist_wm proving ctx");
-  if (!partial_out && !c->have_xstream)
-    return fail(c, G16_ERR_INVALID, "partial_out == NULL needs an exchange stream (g16_partial_buffer hand-off)");
-  return guarded(c, [&]() -> g16_status {
-    hipStream_t s = c->stream;
-    handback(c, c->aux);  // the all-gather of h was enqueued on the exchange stream
-    rank_phase4_enqueue(c, (const U256*)h_all_dev);
-    if (partial_out) {
-      G16_HIP(hipMemcpyAsync(partial_out, c->part_dev(), G16_PARTIAL_BYTES, hipMemcpyDeviceToHost, s));
-      G16_HIP(hipStreamSynchronize(s));
-      collect_times(c);
-    } else {
       G16_HIP(hipStreamWaitEvent(c->xstream, c->ev_part, 0));
     }
     return G16_OK;

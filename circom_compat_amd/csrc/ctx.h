@@ -47,10 +47,11 @@ struct g16_ctx {
   // Sharding of the MSMs over the ranks (options.shard):
   //   point ranges  -- rank g holds the points [w_lo, w_hi) / [h_lo, h_hi) of every query and its own
   //                    (smaller) window configuration;
-  //   bucket ranges -- every rank holds ALL points (w_lo = h_lo = 0) with the single-GPU window and
-  //                    keeps 1/world of the sorted (bucket, point) list (MsmSort::set_shard): the
-  //                    accumulation AND the bucket reduction shrink by world, nothing but the 1 KiB
-  //                    record leaves the device.
+  //   bucket ranges -- the witness-scalar queries (A, B1, B2, L): every rank holds ALL their points
+  //                    (w_lo = 0, w_hi = N - 1) with the single-GPU window and keeps 1/world of the
+  //                    sorted (bucket, point) list (MsmSort::set_shard): the accumulation AND the
+  //                    bucket reduction shrink by world, nothing but the 1 KiB record leaves the
+  //                    device.  The H query stays cut by point range: its scalars are born sharded.
   bool shard_buckets = false;
   // shard of the assignment-index space [0, N-1) (entry i <-> w[1+i]) and of [0, n) for H
   uint32_t w_lo = 0, w_hi = 0, h_lo = 0, h_hi = 0;
@@ -95,11 +96,6 @@ void rank_phase1_enqueue(g16_ctx* c, const uint64_t r[4], const uint64_t s[4], c
                          int32_t* send_dev);
 void rank_phase2_enqueue(g16_ctx* c, const int32_t* recv_dev, int32_t* send_dev);
 void rank_phase3_enqueue(g16_ctx* c, const int32_t* recv_dev);  // ... -> part_dev(), ev_part
-// bucket-range sharding: phase 3 ends with this rank's n / world h scalars in h_out (default: its
-// slice of h_canon), ev_send recorded; after the all-gather phase 4 sorts all n of them (h_all,
-// default h_canon) and runs the rank's share of the H MSM -> part_dev(), ev_part
-void rank_phase3h_enqueue(g16_ctx* c, const int32_t* recv_dev, U256* h_out);
-void rank_phase4_enqueue(g16_ctx* c, const U256* h_all);
 // internal create: `share_from` (same device, same key, bucket-range sharding) lends its point
 // planes; errors come back through *err (never through the process-global message)
 g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,

@@ -58,56 +58,41 @@ MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
 namespace {
 
 
-// bits [bit, bit + c) of a 256-bit scalar (c <= 24).  Selected with compares over the eight words
-// instead of indexing them: a runtime index would move the scalar to scratch memory, i.e. one or
-// two ~1 us memory round trips per digit.
-__device__ __forceinline__ uint32_t window_bits(const U256& sc, int bit, int c) {
-  const int limb = bit >> 5, sh = bit & 31;
-  uint32_t lo = 0, hi = 0;
+// Signed c-bit digits of canonical 256-bit scalars, streamed: the eight words are pushed into a
+// 64-bit bit buffer in order (static word indices: a runtime index would move the scalar to scratch
+// memory, i.e. one or two ~1 us round trips per digit) and a window is cut off whenever c bits are
+// there.  c <= 24, so buffer occupancy stays below 24 + 32 bits.  The window schedule depends on c
+// only: every lane of the grid runs the same control flow, and several scalars can advance in lock
+// step (their LDS ranks / stores overlap).  ~10 instructions per digit; the previous form (select
+// the two words of every window with eight compares) cost ~40, and the level-1 passes are bound by
+// exactly this instruction count once a rank walks ALL scalars to keep an eighth of the digits.
+//   push(k, avail): OR word k of every scalar in flight into its buffer at bit `avail`
+//   step(w):        consume window w (the low c bits) of every buffer
+template <class Push, class Step>
+__device__ __forceinline__ void walk_windows(int c, int W, Push push, Step step) {
+  int avail = 0, w = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    if (k == limb) lo = sc.v[k];
-    if (k == limb + 1) hi = sc.v[k];
-  }
-  const uint64_t two = ((uint64_t)hi << 32) | lo;
-  return (uint32_t)(two >> sh) & ((1u << c) - 1u);
-}
-
-// Walks the signed c-bit digits of canonical scalar i; emit(g, entry) for every non-zero digit.
-template <class Emit>
-__device__ __forceinline__ void for_each_digit(const U256& scalar, uint32_t i, int c, int W, int D,
-                                               uint32_t B, Emit emit) {
-  const uint32_t half = 1u << (c - 1);
-  uint32_t carry = 0;
-  for (int w = 0; w < W; ++w) {
-    uint32_t raw = window_bits(scalar, w * c, c) + carry;
-    uint32_t mag, neg;
-    if (raw > half) {
-      mag = (1u << c) - raw;
-      neg = 1;
-      carry = 1;
-    } else {
-      mag = raw;
-      neg = 0;
-      carry = 0;
-    }
-    if (mag) {
-      const uint32_t d = (uint32_t)(w % D), j = (uint32_t)(w / D);
-      emit(d * B + (mag - 1), i | (j << MSM_IDX_BITS) | (neg << 31));
+    push(k, avail);
+    avail += 32;
+    while (avail >= c && w < W) {
+      step(w);
+      avail -= c;
+      ++w;
     }
   }
+  if (w < W) step(w);  // W c >= 255 > 256 - c: at most one window is left, its missing top bits are zero
 }
 
-// The same walk one window at a time (state = the carry), so that several scalars can advance in
-// lock step and their LDS ranks / stores overlap.
-struct DigitWalker {
-  U256 sc;
+struct DigitState {
+  uint64_t buf = 0;
   uint32_t carry = 0;
-  // window w of scalar i: returns false for a zero digit
-  __device__ __forceinline__ bool next(int w, uint32_t i, int c, int D, uint32_t B, uint32_t* g,
+  // window w of scalar i (the low c bits of buf): false for a zero digit
+  __device__ __forceinline__ bool take(int w, uint32_t i, int c, int D, uint32_t B, uint32_t* g,
                                        uint32_t* entry) {
     const uint32_t half = 1u << (c - 1);
-    const uint32_t raw = window_bits(sc, w * c, c) + carry;
+    const uint32_t raw = ((uint32_t)buf & ((1u << c) - 1u)) + carry;
+    buf >>= c;
     uint32_t mag, neg;
     if (raw > half) {
       mag = (1u << c) - raw;
@@ -125,6 +110,19 @@ struct DigitWalker {
     return true;
   }
 };
+
+// Walks the signed c-bit digits of canonical scalar i; emit(g, entry) for every non-zero digit.
+template <class Emit>
+__device__ __forceinline__ void for_each_digit(const U256& scalar, uint32_t i, int c, int W, int D,
+                                               uint32_t B, Emit emit) {
+  DigitState st;
+  walk_windows(
+      c, W, [&](int k, int avail) { st.buf |= (uint64_t)scalar.v[k] << avail; },
+      [&](int w) {
+        uint32_t g, e;
+        if (st.take(w, i, c, D, B, &g, &e)) emit(g, e);
+      });
+}
 
 // ---- two-level counting sort of the (bucket, entry) pairs ---------------------------------------
 // A single-level sort needs one global atomic per entry and per pass (2 x 58.7 M at n = 2^22:
@@ -179,21 +177,24 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_count(const void* scalars, 
 // A partition joins the current run when that brings the run closer to its target (the remaining
 // entries over the remaining ranks, so rounding never accumulates); one hot partition larger than a
 // fair share gets a rank to itself.
-__global__ void k_pick_range(const uint32_t* part_off, uint32_t bins1, int sh, uint32_t nb, int rank,
-                             int world, uint32_t* range) {
+__global__ void __launch_bounds__(256) k_pick_range(const uint32_t* part_off, uint32_t bins1, int sh,
+                                                    uint32_t nb, int rank, int world, uint32_t* range) {
+  __shared__ uint32_t off[P1_MAX_BINS + 1];  // staged by the block: the walk below is one lane's serial chain
+  for (uint32_t b = threadIdx.x; b <= bins1; b += blockDim.x) off[b] = part_off[b];
+  __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const uint32_t M = part_off[bins1];
+  const uint32_t M = off[bins1];
   uint32_t p = 0, lo = 0, hi = 0;
   for (int g = 0; g <= rank; ++g) {
     lo = p;
     if (g == world - 1) {
       p = bins1;
     } else {
-      const uint64_t rem = (uint64_t)M - part_off[p];
+      const uint64_t rem = (uint64_t)M - off[p];
       const uint64_t tgt = rem / (uint64_t)(world - g);
       uint64_t acc = 0;
       while (p < bins1) {
-        const uint64_t cnt = (uint64_t)part_off[p + 1] - part_off[p];
+        const uint64_t cnt = (uint64_t)off[p + 1] - off[p];
         if (acc + cnt / 2 > tgt && !(acc == 0 && cnt != 0 && tgt != 0)) break;
         acc += cnt;
         ++p;
@@ -203,8 +204,8 @@ __global__ void k_pick_range(const uint32_t* part_off, uint32_t bins1, int sh, u
   }
   range[0] = lo;
   range[1] = hi;
-  range[2] = part_off[lo];
-  range[3] = part_off[hi] - part_off[lo];
+  range[2] = off[lo];
+  range[3] = off[hi] - off[lo];
   const uint64_t b_lo = (uint64_t)lo << sh, b_hi = (uint64_t)hi << sh;
   range[4] = (uint32_t)(b_lo < nb ? b_lo : nb);
   range[5] = (uint32_t)(b_hi < nb ? b_hi : nb);
@@ -235,6 +236,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
       idx[k] = tile * P1_TILE + (uint32_t)k * P1_THREADS + tid;
       live[k] = idx[k] < n;
       if (live[k]) sc[k] = load_scalar<MONT>(scalars, idx[k]);
+      else sc[k] = U256{};
     }
     __syncthreads();
 #pragma unroll
@@ -257,25 +259,29 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
     static_assert(P1_PER_THREAD % U == 0, "P1_PER_THREAD must be a multiple of the unroll");
 #pragma unroll
     for (int k0 = 0; k0 < P1_PER_THREAD; k0 += U) {
-      DigitWalker wk[U];
+      DigitState wk[U];
+      walk_windows(
+          G.c, G.W,
+          [&](int k, int avail) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) wk[u].sc = sc[k0 + u];
-      for (int w = 0; w < G.W; ++w) {
-        uint32_t g[U], e[U], pos[U];
-        bool v[U];
+            for (int u = 0; u < U; ++u) wk[u].buf |= (uint64_t)sc[k0 + u].v[k] << avail;
+          },
+          [&](int w) {
+            uint32_t g[U], e[U], pos[U];
+            bool v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          v[u] = live[k0 + u] && wk[u].next(w, idx[k0 + u], G.c, G.D, G.B, &g[u], &e[u]);
-          if (v[u]) {
-            const uint32_t pb = g[u] >> G.sh;
-            v[u] = pb >= p_lo && pb < p_hi;
-            if (v[u]) pos[u] = atomicAdd(&h[pb], 1u);
-          }
-        }
+            for (int u = 0; u < U; ++u) {
+              v[u] = wk[u].take(w, idx[k0 + u], G.c, G.D, G.B, &g[u], &e[u]) && live[k0 + u];
+              if (v[u]) {
+                const uint32_t pb = g[u] >> G.sh;
+                v[u] = pb >= p_lo && pb < p_hi;
+                if (v[u]) pos[u] = atomicAdd(&h[pb], 1u);
+              }
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (v[u]) part[pos[u]] = MsmPair{e[u], g[u]};
-      }
+            for (int u = 0; u < U; ++u)
+              if (v[u]) part[pos[u]] = MsmPair{e[u], g[u]};
+          });
     }
     __syncthreads();
   }
@@ -536,7 +542,7 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
   scan_exclusive(gcount1.p, G.bins1, 0, part_off.p, cursor1.p, scan_tmp.p, s);
   const uint32_t* rng = range_dev();
   if (rng)
-    G16_LAUNCH(k_pick_range, 1, 64, 0, s, (const uint32_t*)part_off.p, G.bins1, G.sh, nb, rank, world,
+    G16_LAUNCH(k_pick_range, 1, 256, 0, s, (const uint32_t*)part_off.p, G.bins1, G.sh, nb, rank, world,
                range.p);
   if (mont)
     G16_LAUNCH((k_part_scatter<true>), grid1, P1_THREADS, 0, s, scalars, n, G, cursor1.p, part.p, rng);

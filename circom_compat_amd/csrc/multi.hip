@@ -175,9 +175,7 @@ struct Multi {
   struct Dev {
     DevBuf<int32_t> send[2], recv[2];
     std::vector<hipStream_t> cs;            // one copy stream per destination
-    // [exchange][dst]: my chunk has landed in dst's buffer.  Exchanges 0, 1: the all-to-all
-    // transposes of the witness map; 2: the all-gather of h (bucket-range sharding)
-    std::vector<hipEvent_t> arrived[3];
+    std::vector<hipEvent_t> arrived[2];     // [exchange][dst]: my chunk has landed in dst's recv buffer
   };
   std::vector<std::unique_ptr<Dev>> dv;  // DevBuf is not movable
   bool witness_resident = false;  // g16_witness_upload: every child's w_dev holds the current witness
@@ -228,23 +226,6 @@ void push_chunks(Multi& M, int g, int x) {
     G16_HIP(hipMemcpyPeerAsync(M.dv[d]->recv[x].p + (size_t)g * M.chunk_ints, M.ch[d]->device,
                                me.send[x].p + (size_t)d * M.chunk_ints, c->device, bytes, st));
     G16_HIP(hipEventRecord(me.arrived[x][d], st));
-  }
-}
-
-// all-gather of h (bucket-range sharding): rank g's n / G scalars sit in its own h_canon slice
-// (phase 3 wrote them there) and are pushed into the same slice of every peer's h_canon
-void push_h(Multi& M, int g) {
-  g16_ctx* c = M.ch[g];
-  Multi::Dev& me = *M.dv[g];
-  const size_t per = c->n / (size_t)M.G;
-  for (int k = 0; k < M.G; ++k) {
-    const int d = (g + k) % M.G;
-    hipStream_t st = me.cs[d];
-    G16_HIP(hipStreamWaitEvent(st, c->ev_send, 0));
-    if (d != g)
-      G16_HIP(hipMemcpyPeerAsync(M.ch[d]->h_canon.p + (size_t)g * per, M.ch[d]->device,
-                                 c->h_canon.p + (size_t)g * per, c->device, per * sizeof(U256), st));
-    G16_HIP(hipEventRecord(me.arrived[2][d], st));
   }
 }
 
@@ -359,7 +340,7 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
     G16_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     d.cs.assign(n_dev, nullptr);
     for (auto& s2 : d.cs) G16_HIP(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio_hi));
-    for (int x = 0; x < 3; ++x) {
+    for (int x = 0; x < 2; ++x) {
       d.arrived[x].assign(n_dev, nullptr);
       for (auto& e : d.arrived[x]) G16_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
@@ -474,25 +455,11 @@ g16_status multi_prove(g16_ctx* parent, const uint64_t r[4], const uint64_t s_[4
       rank_phase2_enqueue(M.ch[g], M.dv[g]->recv[0].p, M.dv[g]->send[1].p);
       push_chunks(M, g, 1);
     });
-    if (M.buckets) {
-      st.push_back([&](int g) {
-        G16_HIP(hipSetDevice(M.ch[g]->device));
-        await_chunks(M, g, 1, M.ch[g]->aux);
-        rank_phase3h_enqueue(M.ch[g], M.dv[g]->recv[1].p, nullptr);
-        push_h(M, g);
-      });
-      st.push_back([&](int g) {
-        G16_HIP(hipSetDevice(M.ch[g]->device));
-        await_chunks(M, g, 2, M.ch[g]->aux);
-        rank_phase4_enqueue(M.ch[g], nullptr);
-      });
-    } else {
-      st.push_back([&](int g) {
-        G16_HIP(hipSetDevice(M.ch[g]->device));
-        await_chunks(M, g, 1, M.ch[g]->aux);
-        rank_phase3_enqueue(M.ch[g], M.dv[g]->recv[1].p);
-      });
-    }
+    st.push_back([&](int g) {
+      G16_HIP(hipSetDevice(M.ch[g]->device));
+      await_chunks(M, g, 1, M.ch[g]->aux);
+      rank_phase3_enqueue(M.ch[g], M.dv[g]->recv[1].p);
+    });
   } else {
     st.push_back([&](int g) {
       stage_witness(g);

@@ -34,8 +34,7 @@ struct WmDist {
   void init(const CsrHost& A, const CsrHost& B, uint32_t m, uint32_t num_inputs, int rank, int world);
   size_t exchange_ints() const { return (size_t)3 * c2 * n1 * NTT29_LIMBS; }  // per rank, per exchange
   // global evaluation index e of local h index t (the H-query shard of this rank)
-  uint32_t global_index(uint32_t t) const { return global_index_of(rank, t); }
-  uint32_t global_index_of(int rk, uint32_t t) const { return (uint32_t)rk * c2 + t / n1 + n2 * (t % n1); }
+  uint32_t global_index(uint32_t t) const { return (uint32_t)rank * c2 + t / n1 + n2 * (t % n1); }
   void phase1(const Fr* w_dev, int32_t* send, hipStream_t stream);
   void phase2(const int32_t* recv, int32_t* send, hipStream_t stream);
   void phase3(const int32_t* recv, U256* h_canon, hipStream_t stream);  // n / G canonical scalars

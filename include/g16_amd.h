@@ -79,13 +79,16 @@ typedef struct {
 /* How the MSMs of one proof are cut over `world` ranks:
  *   POINTS   every query array by contiguous point range; a rank sorts and accumulates its n/world
  *            points with the window that suits n/world (more windows, a bucket set per rank);
- *   BUCKETS  every rank keeps the whole key resident (sized for 288 GB: 21 GiB at 2^22, 84 GiB at
+ *   BUCKETS  the four witness-scalar queries (A, B1, B2, L -- the witness is resident on every rank
+ *            anyway): every rank keeps ALL their points (sized for 288 GB: 18 GiB at 2^22, 72 GiB at
  *            2^24) and the single-GPU window; the sorted (bucket, point) list is cut into `world`
  *            equal runs of whole sort partitions, chosen on the device from the digit histogram, and
  *            rank g accumulates and reduces run g only.  Same additions per point as on one GPU,
  *            1/world of the bucket reduction per rank, and no bucket sums on the links: the only MSM
- *            traffic is the 1 KiB record per rank (plus the all-gather of h, 32 n bytes per rank).
- *   AUTO     BUCKETS when the full planes of the whole key fit the device, else POINTS.            */
+ *            traffic is the 1 KiB record per rank.  The H query stays cut by point range -- its
+ *            scalars are born sharded (the distributed witness map leaves rank g its n / world
+ *            evaluations), moving them would put the whole vector on every link.
+ *   AUTO     BUCKETS when the full planes of the witness queries fit the device, else POINTS.      */
 enum { G16_SHARD_AUTO = 0, G16_SHARD_POINTS = 1, G16_SHARD_BUCKETS = 2 };
 
 /* The R1CS -> QAP reduction (the `QAP` type parameter of ark_groth16::Groth16<E, QAP>):
@@ -199,19 +202,6 @@ g16_status g16_prove_dist_phase2(g16_ctx* ctx, const void* recv_dev, void* send_
 /* partial_out may be NULL when an exchange stream is registered: the record then stays in
  * g16_partial_buffer() and the registered stream waits for it.                                     */
 g16_status g16_prove_dist_phase3(g16_ctx* ctx, const void* recv_dev,
-                                 uint8_t partial_out[G16_PARTIAL_BYTES]);
-
-/* Bucket-sharded ranks (options.shard = G16_SHARD_BUCKETS, or AUTO when the whole key fits): the H MSM
- * needs all n h scalars on every rank, so phase 3 is followed by an all-gather and a fourth phase:
- *   ... exchange 2 -> phase3h(recv, h_send) -> all-gather of g16_dist_h_bytes() bytes per rank
- *   -> phase4(h_all, partial_out) -> all-gather of the partial records -> g16_prove_finish[_dev].
- * h_send NULL: the rank's slice of g16_h_gather_buffer() (n x 32 bytes, rank order) -- an in-place
- * all-gather (ncclAllGather with sendbuff = recvbuff + rank * count) then needs no copy; h_all NULL:
- * that same buffer.  The H query is held in the order the all-gather delivers the scalars.         */
-size_t g16_dist_h_bytes(const g16_ctx* ctx);
-void* g16_h_gather_buffer(g16_ctx* ctx);
-g16_status g16_prove_dist_phase3h(g16_ctx* ctx, const void* recv_dev, void* h_send_dev);
-g16_status g16_prove_dist_phase4(g16_ctx* ctx, const void* h_all_dev,
                                  uint8_t partial_out[G16_PARTIAL_BYTES]);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------ */

@@ -9,8 +9,8 @@ rank sends per proof and the link time they take at a stated per-link rate are p
     python scripts/dist_projection.py [log2=22] [worlds=2,4,8] [reps=5] [modes=points,buckets]
 
 modes: points  = MSMs cut by point range (rank 0 is timed: all ranks alike)
-       buckets = MSMs cut by bucket range (every rank holds the whole key; the slowest of rank 0 --
-                 the dense low partitions, fewest buckets -- and a middle rank is reported)"""
+       buckets = witness-scalar MSMs cut by bucket range (every rank holds all A/B1/B2/L points; the
+                 slowest of rank 0 -- the dense low partitions, fewest buckets -- and a middle rank)"""
 import json
 import os
 import random
@@ -75,16 +75,6 @@ def one_rank(G, mode, rank):
     recv = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
     part = cc.device_tensor(p.partial_buffer(), 1024)
     gath = cc.device_tensor(p.gather_buffer(), G * 1024)
-    hb = p.h_bytes()
-    if mode == "buckets":
-        # the other ranks' h scalars: uniform 253-bit values (what the sort and the H MSM see on a real node)
-        h_all = cc.device_tensor(p.h_gather_buffer(), G * hb)
-        fill = torch.randint(0, 1 << 62, (G * hb // 8,), dtype=torch.int64, device="cuda")
-        fill[3::4] &= (1 << 60) - 1
-        h_all.copy_(fill.view(torch.uint8))
-        h_tmp = torch.empty(hb, dtype=torch.uint8, device="cuda")
-        del fill
-
     def rank_step():
         p.dist_phase1(rs[0], rs[1], w_dev.data_ptr(), send.data_ptr())
         with torch.cuda.stream(xs):
@@ -92,14 +82,7 @@ def one_rank(G, mode, rank):
         p.dist_phase2(recv.data_ptr(), send.data_ptr())
         with torch.cuda.stream(xs):
             recv.copy_(send, non_blocking=True)
-        if mode == "points":
-            p.dist_phase3_dev(recv.data_ptr())
-        else:
-            p.dist_phase3h(recv.data_ptr())
-            with torch.cuda.stream(xs):          # stands in for the G - 1 slices arriving from the peers
-                for g in range(G - 1):
-                    h_tmp.copy_(h_all[g * hb:(g + 1) * hb], non_blocking=True)
-            p.dist_phase4_dev()
+        p.dist_phase3_dev(recv.data_ptr())
         with torch.cuda.stream(xs):
             for g in range(G):
                 gath[g * 1024:(g + 1) * 1024].copy_(part, non_blocking=True)
@@ -112,8 +95,8 @@ def one_rank(G, mode, rank):
     torch.cuda.synchronize()
     stages = {n: round(ms, 3) for n, (ms, _c) in p.stage_times().items()}
     p.close()
-    # bytes this rank SENDS per proof: (G-1)/G of each all-to-all buffer, its h slice to G-1 peers
-    sent = 2 * nbytes * (G - 1) / G + (hb * (G - 1) if mode == "buckets" else 0)
+    # bytes this rank SENDS per proof: (G-1)/G of each all-to-all buffer (+ 1 KiB records)
+    sent = 2 * nbytes * (G - 1) / G
     links = min(G - 1, 7)
     return tr, info, stages, sent, sent / links / (LINK_GBS * 1e9) * 1e3
 

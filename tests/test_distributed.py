@@ -1,6 +1,6 @@
 """world_size = 2 and 4 over gloo on the CPU: the sharded paths (per-rank MSM partials over point
 ranges and over bucket ranges -> all_gather -> local EC add -> finish; distributed witness map with
-its all-to-all exchanges and, for bucket ranges, the all-gather of h) give the oracle's proof bytes.
+its two all-to-all exchanges) give the oracle's proof bytes.
 Runs the kernel sources on the SIMT emulator (tests only); on the GPU the same harness code in
 bench.py uses backend nccl (= RCCL)."""
 import os
@@ -69,9 +69,9 @@ WORKER = textwrap.dedent('''
     g3 = torch.empty(world * 1024, dtype=torch.uint8)
     dist.all_gather_into_tensor(g3, torch.frombuffer(bytearray(pb.prove_partial(r, s, w)), dtype=torch.uint8))
     assert pb.prove_finish(r, s, g3.numpy().tobytes()).raw == o.proof_to_bytes(want), "bucket-sharded proof differs"
-    # ... then fully sharded: phases 1-2 as above, phase 3 leaves this rank's h scalars, all-gather of
-    # h, phase 4 = the rank's share of the H MSM
+    # ... then fully sharded: the same three phases and two exchanges as the point-range ranks
     pq = cc.Prover(pk, mats, lib=lib, rank=rank, world=world, dist_wm=True, shard="buckets")
+    assert pq.info()["shard_mode"] == "buckets" and pq.info()["shard_h"] == pk.domain_size // world
     nbytes = pq.exchange_bytes()
     send = torch.empty(nbytes, dtype=torch.uint8)
     recv = torch.empty(nbytes, dtype=torch.uint8)
@@ -79,12 +79,7 @@ WORKER = textwrap.dedent('''
     dist.all_to_all_single(recv, send)
     pq.dist_phase2(recv.data_ptr(), send.data_ptr())
     dist.all_to_all_single(recv, send)
-    h_mine = torch.empty(pq.h_bytes(), dtype=torch.uint8)
-    h_all = torch.empty(world * pq.h_bytes(), dtype=torch.uint8)
-    assert h_all.numel() == 32 * pk.domain_size
-    pq.dist_phase3h(recv.data_ptr(), h_mine.data_ptr())
-    dist.all_gather_into_tensor(h_all, h_mine)
-    part4 = pq.dist_phase4(h_all.data_ptr())
+    part4 = pq.dist_phase3(recv.data_ptr())
     g4 = torch.empty(world * 1024, dtype=torch.uint8)
     dist.all_gather_into_tensor(g4, torch.frombuffer(bytearray(part4), dtype=torch.uint8))
     assert pq.prove_finish(r, s, g4.numpy().tobytes()).raw == o.proof_to_bytes(want), "fully bucket-sharded proof differs"

@@ -136,9 +136,9 @@ def test_determinism(gpulib, golden):
 @pytest.mark.parametrize("logm,world", [(10, 2), (14, 4), (16, 8)])
 def test_fully_sharded_prover_emulated_ranks_one_gpu(gpulib, logm, world, shard):
     """The fully sharded prover through the per-process API (distributed witness map + MSMs sharded by
-    point range or by bucket range) with all `world` ranks living on ONE GPU: the all-to-all exchanges
-    (and the all-gather of h under bucket ranges) are done by hand on device tensors.  The proof must
-    be bit-identical to the CPU restatement's proof of the same (pk, r, s, w)."""
+    point range or -- the witness-scalar queries -- by bucket range) with all `world` ranks living on
+    ONE GPU: the two all-to-all exchanges are done by hand on device tensors.  The proof must be
+    bit-identical to the CPU restatement's proof of the same (pk, r, s, w)."""
     import torch
     import circom_compat_amd as cc
     import cpu_ref
@@ -172,16 +172,7 @@ def test_fully_sharded_prover_emulated_ranks_one_gpu(gpulib, logm, world, shard)
     for g, p in enumerate(provers):
         p.dist_phase2(recv[g].data_ptr(), send[g].data_ptr())
     all_to_all()
-    if shard == "points":
-        parts = b"".join(p.dist_phase3(recv[g].data_ptr()) for g, p in enumerate(provers))
-    else:
-        hb = provers[0].h_bytes()
-        assert hb * world == 32 * pk.domain_size
-        h_all = torch.empty(hb * world, dtype=torch.uint8, device="cuda")
-        for g, p in enumerate(provers):                       # all-gather: every rank's slice, rank order
-            p.dist_phase3h(recv[g].data_ptr(), h_all[g * hb:(g + 1) * hb].data_ptr())
-        torch.cuda.synchronize()
-        parts = b"".join(p.dist_phase4(h_all.data_ptr()) for p in provers)
+    parts = b"".join(p.dist_phase3(recv[g].data_ptr()) for g, p in enumerate(provers))
     proof = provers[0].prove_finish(r, s, parts)
     assert proof.raw == want
     assert o.verify_proof(_vk_dict(pk), [w_ints[1]], H.proof_from_bytes(proof.raw))
@@ -314,7 +305,7 @@ def test_full_prove_headline_sizes_bytes_pairing_and_qap_identities(gpulib, k):
     assert pr.msm_g1(3, cc.fr_from_ints(h)) == o.g1_to_bytes(o.G1.mul(o.G1_GEN, lhs))
     # ---- BASELINE configs[3] as far as one GPU allows: the SAME circuit sharded over 8 ranks
     # (g16_ctx_create_multi, every rank on this GPU, MSMs cut by bucket range, distributed witness
-    # map, h all-gather): bytes == the CPU proof above; a second proof with other (r, s) verifies
+    # map): bytes == the CPU proof above; a second proof with other (r, s) verifies
     if k >= 22:
         pr.close()
         del pr
@@ -380,7 +371,6 @@ def test_per_rank_api_with_exchange_stream_no_host_syncs(gpulib, shard):
     provers = [cc.Prover(pk, mats, rank=g, world=world, dist_wm=True, shard=shard) for g in range(world)]
     for p in provers:
         p.set_exchange_stream(xs.cuda_stream)
-    hb = provers[0].h_bytes()
     nbytes = provers[0].exchange_bytes()
     chunk = nbytes // world
     send = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(world)]
@@ -401,22 +391,8 @@ def test_per_rank_api_with_exchange_stream_no_host_syncs(gpulib, shard):
         for g, p in enumerate(provers):
             p.dist_phase2(recv[g].data_ptr(), send[g].data_ptr())
         all_to_all()
-        if shard == "points":
-            for g, p in enumerate(provers):
-                p.dist_phase3_dev(recv[g].data_ptr())
-        else:
-            for g, p in enumerate(provers):                 # h shard left in the rank's own slice
-                p.dist_phase3h(recv[g].data_ptr())
-            with torch.cuda.stream(xs):                     # all-gather of h, device to device
-                for dst in provers:
-                    out = cc.device_tensor(dst.h_gather_buffer(), world * hb)
-                    for g, src in enumerate(provers):
-                        if src is not dst:
-                            out[g * hb:(g + 1) * hb].copy_(
-                                cc.device_tensor(src.h_gather_buffer(), world * hb)[g * hb:(g + 1) * hb],
-                                non_blocking=True)
-            for p in provers:
-                p.dist_phase4_dev()
+        for g, p in enumerate(provers):
+            p.dist_phase3_dev(recv[g].data_ptr())
         # all-gather of the 1 KiB records, device to device on the registered stream
         with torch.cuda.stream(xs):
             for dst in provers:
@@ -582,16 +558,7 @@ for shard in ("points", "buckets"):
         p.dist_phase2(recv.data_ptr(), send.data_ptr())
         with torch.cuda.stream(xs):
             dist.all_to_all_single(recv, send)
-        if shard == "points":
-            p.dist_phase3_dev(recv.data_ptr())
-        else:
-            hb = p.h_bytes()
-            h_mine = torch.empty(hb, dtype=torch.uint8, device="cuda")
-            h_all = torch.empty(hb, dtype=torch.uint8, device="cuda")
-            p.dist_phase3h(recv.data_ptr(), h_mine.data_ptr())
-            with torch.cuda.stream(xs):
-                dist.all_gather_into_tensor(h_all, h_mine)
-            p.dist_phase4_dev(h_all.data_ptr())
+        p.dist_phase3_dev(recv.data_ptr())
         with torch.cuda.stream(xs):
             dist.all_gather_into_tensor(gath_t, part_t)
         proof = p.prove_finish_dev(rs[0], rs[1])
@@ -606,8 +573,8 @@ dist.destroy_process_group()
 
 def test_rccl_executes_next_to_the_library_world1(gpulib, tmp_path):
     """RCCL (torch backend "nccl") loaded and executing in the same process as libg16_amd.so: a
-    one-rank process group drives the per-process phase API -- all_to_all_single twice,
-    all_gather_into_tensor of h (bucket mode) and of the 1 KiB records -- on the registered
+    one-rank process group drives the per-process phase API -- all_to_all_single twice and
+    all_gather_into_tensor of the 1 KiB records -- on the registered
     high-priority stream, with the library's event hand-offs on both sides of every collective.
     Degenerate exchanges (one rank), real code path: the first 8-GPU run is not the first time the
     two libraries meet.  bytes == CPU restatement, two consecutive proofs per shard mode."""

@@ -445,8 +445,7 @@ def test_error_paths_through_the_abi(lib, golden):
 def test_in_library_multi_device_prover(lib, logm, devices, shard):
     """g16_ctx_create_multi: one ctx, the ranks (MSMs sharded by point range or by bucket range +
     distributed witness map for power-of-two device counts, replicated witness map otherwise) and
-    every exchange (two all-to-all, the all-gather of h under bucket ranges) and the gather live
-    inside the library -- no host framework, no collective library.  Every listed device is ordinal 0
+    both all-to-all exchanges and the gather live inside the library -- no host framework, no collective library.  Every listed device is ordinal 0
     here (ranks time-sharing one device; bucket-sharded ranks borrow rank 0's planes); the proof must
     equal the oracle's, and two consecutive proofs with different (r, s) cover buffer / event reuse."""
     import circom_compat_amd as cc
@@ -613,8 +612,8 @@ def test_bucket_range_sharding_windows_planes_and_skew(lib, logm, world, wb, pla
     windows large enough for multi-bucket partitions (c = 13, 14: the reduction's chunk grid anchored
     at the run start), fewer planes than windows (several bucket sets, D = 7, D = W: a run spans
     sets), a skewed 0/1-heavy witness (one partition holds most entries: a rank may own one partition
-    or none), world = 3 (replicated witness map, no h all-gather), 8 ranks on 64 points.  bytes ==
-    oracle, two proofs."""
+    or none), world = 3 (replicated witness map), 8 ranks on 64 points.  bytes == oracle, two
+    proofs."""
     import circom_compat_amd as cc
     if lib.path.endswith("libg16_emu.so") and wb >= 14 and world >= 8:
         world = 4                                    # the emulator steps through every rank's 2^13-bucket sets
@@ -631,7 +630,8 @@ def test_bucket_range_sharding_windows_planes_and_skew(lib, logm, world, wb, pla
     pr = cc.Prover(H.pk_from_oracle(opk), mats, lib=lib, devices=[0] * world, shard="buckets",
                    window_bits=wb, planes=planes)
     info = pr.info()
-    assert info["shard_mode"] == "buckets" and info["shard_w"] == n_vars - 1 and info["shard_h"] == info["domain_size"]
+    assert info["shard_mode"] == "buckets" and info["shard_w"] == n_vars - 1
+    assert info["shard_h"] == info["domain_size"] // world      # H stays cut by point range
     if wb:
         assert info["c_w"] == wb
     for _ in range(2):
