@@ -642,53 +642,74 @@ def main():
                                   + " (arkworks itself is not buildable offline)",
                         "host_cpu_count": os.cpu_count()})
 
-    # ---------------- roofline of the dominant kernel (k_bucket_accumulate<Fq>) ----------------
-    # G1 accumulation launches of a proof: ONE over the interleaved A|B1 pair (its own stage) and one
-    # each for L and H -- the single-query launches are the roofline's kernel, the pair is beside it
+    # ---------------- roofline: the three instantiations of k_bucket_accumulate ----------------
+    # A proof launches it four times: <Fq2, 1, false> for B2 (the longest launch of a step: the line's
+    # `roofline.kernel`), <Fq, 2, true> once over the interleaved A|B1 pair, <Fq, 1, false> for L and H.
+    # Algorithmic bytes: point + 32-byte scalar per point of the query.
+    g2_ms, g2_cnt = stages.get("msm_accumulate_g2", (0.0, 0))
     acc_ms, acc_cnt = stages["msm_accumulate_g1"]
     pair_ms, pair_cnt = stages.get("msm_accumulate_g1_pair", (0.0, 0))
-    per_launch_ms = acc_ms / max(acc_cnt, 1)
-    # one G1 MSM of length L = 96 L algorithmic bytes (64 B point + 32 B scalar)
     shard_w, shard_h = info["shard_w"], info["shard_h"]
     W_w, W_h = info["W_w"], info["W_h"]
-    if pair_cnt:
-        avg_len = (shard_w + shard_h) / 2.0                      # L and H
-        madds = (shard_w * W_w + shard_h * W_h) / 2.0
-    else:                                                        # G16_NO_PAIR_AB=1: A, B1, L and H
-        avg_len = (3 * shard_w + shard_h) / 4.0
-        madds = (3 * shard_w * W_w + shard_h * W_h) / 4.0        # mixed additions per launch (upper bound)
-    alg_bytes = 96.0 * avg_len
-    achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-    traffic = pair_traffic = None
+    import hashlib
+    lib_sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:16]
+    pmc, pmc_note = {}, "no PMC record for this size / workload"
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if n_gpus == 1 and os.path.exists(tpath) and args.workload == "chain":
         t = json.load(open(tpath))
-        if t.get("log2_domain") == k:
-            traffic = t["traffic_bytes_per_launch"]
-            pair_traffic = t.get("pair_traffic_bytes_per_launch")
-    kname = "k_bucket_accumulate<Fq, 1, false>" if pair_cnt else "k_bucket_accumulate<Fq>"
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_unit": "bytes per launch (PMC: profiles/pmc_traffic.json)",
-                "avg_launch_ms": per_launch_ms, "launches_per_step": acc_cnt / args.steps,
-                "algorithmic_bytes_per_launch": alg_bytes,
+        if t.get("log2_domain") != k:
+            pmc_note = f"profiles/pmc_traffic.json was measured at 2^{t.get('log2_domain')}"
+        elif t.get("library_sha16") != lib_sha:
+            pmc_note = (f"profiles/pmc_traffic.json was measured on library {t.get('library_sha16')}, this run "
+                        f"loaded {lib_sha}: traffic dropped (re-run scripts/pmc_passes.sh + scripts/pmc_traffic.py)")
+        else:
+            pmc = t
+            pmc_note = (f"separate rocprofv3 --pmc passes (scripts/pmc_passes.sh) on library {lib_sha}, "
+                        f"{t.get('measured', '?')}; NOT measured by this run")
+
+    def kern(name, what, ms, cnt, bytes_per_point, npoints, madds, vmad_per_madd, tkey):
+        if not cnt or ms <= 0:
+            return None
+        per = ms / cnt
+        algb = float(bytes_per_point) * npoints
+        ach = algb / (per * 1e-3) / 1e9
+        return {"kernel": name, "what": what, "avg_launch_ms": per, "launches_per_step": cnt / args.steps,
+                "algorithmic_bytes_per_launch": algb, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                "traffic": pmc.get(tkey), "mixed_additions_per_s": madds / (per * 1e-3),
+                "vmad_frac_of_issue_peak": madds * vmad_per_madd / (per * 1e-3) / 30.1e12}
+    VMAD_G1, VMAD_G2 = 1557.0, 4878.0          # multiply-adds per mixed addition
+    if pair_cnt:
+        g1_len, g1_madds = (shard_w + shard_h) / 2.0, (shard_w * W_w + shard_h * W_h) / 2.0   # L and H
+    else:                                       # G16_NO_PAIR_AB=1: A, B1, L and H
+        g1_len, g1_madds = (3 * shard_w + shard_h) / 4.0, (3 * shard_w * W_w + shard_h * W_h) / 4.0
+    kerns = [kern("k_bucket_accumulate<Fq2, 1, false>", "B2 query (G2)", g2_ms, g2_cnt, 160, shard_w,
+                  shard_w * W_w, VMAD_G2, "g2_traffic_bytes_per_launch"),
+             kern("k_bucket_accumulate<Fq, 2, true>", "A and B1 over the interleaved A_i|B1_i records", pair_ms,
+                  pair_cnt, 160, shard_w, 2 * shard_w * W_w, VMAD_G1, "pair_traffic_bytes_per_launch"),
+             kern("k_bucket_accumulate<Fq, 1, false>", "L and H queries" if pair_cnt else "A, B1, L, H queries",
+                  acc_ms, acc_cnt, 96, g1_len, g1_madds, VMAD_G1, "traffic_bytes_per_launch")]
+    kerns = [x for x in kerns if x]
+    head = max(kerns, key=lambda x: x["avg_launch_ms"])        # the per-step dominant launch
+    tot_b = sum(x["algorithmic_bytes_per_launch"] * x["launches_per_step"] for x in kerns)
+    tot_ms = sum(x["avg_launch_ms"] * x["launches_per_step"] for x in kerns)
+    roofline = {"bound": "hbm", "kernel": head["kernel"], "achieved": head["achieved"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": head["frac"], "traffic": head["traffic"],
+                "traffic_unit": "HBM bytes per launch", "traffic_source": pmc_note,
+                "avg_launch_ms": head["avg_launch_ms"], "launches_per_step": head["launches_per_step"],
+                "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
+                "all_accumulate_launches": kerns,
+                "time_weighted": {"achieved": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0,
+                                  "frac": tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tot_ms else 0.0,
+                                  "accumulate_ms_per_step": tot_ms},
+                "library_sha16": lib_sha,
                 "note": "the kernel is integer-ALU bound (254-bit Montgomery arithmetic on v_mad_i64_i32), "
                         "not HBM bound: see `alu` and DESIGN.md section 4-5"}
-    if pair_cnt:
-        pms = pair_ms / pair_cnt
-        pbytes = (64.0 + 64.0 + 32.0) * shard_w      # two points + the scalar they share
-        roofline["pair_launch"] = {
-            "kernel": "k_bucket_accumulate<Fq, 2, true>", "what": "A and B1 over the interleaved A_i|B1_i records",
-            "avg_launch_ms": pms, "launches_per_step": pair_cnt / args.steps,
-            "algorithmic_bytes_per_launch": pbytes, "achieved": pbytes / (pms * 1e-3) / 1e9,
-            "frac": pbytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pair_traffic}
     # supplementary: the same launches against the micro-benchmarked integer multiply-add issue peak
-    VMAD_PER_MADD = 1557.0                                     # 8 products + 2 squarings on 9x29-bit limbs
-    VMAD_PEAK = 30.1e12                                        # profiles/r01_instr_rates.txt
-    alu = {"kernel": kname, "mixed_additions_per_s": madds / (per_launch_ms * 1e-3),
-           "vmad_per_s": madds * VMAD_PER_MADD / (per_launch_ms * 1e-3), "vmad_peak_per_s": VMAD_PEAK,
-           "frac": madds * VMAD_PER_MADD / (per_launch_ms * 1e-3) / VMAD_PEAK,
-           "alu_only_ceiling_mixed_additions_per_s": 16.7e9}
+    g1k = next((x for x in kerns if x["kernel"].startswith("k_bucket_accumulate<Fq, 1")), head)
+    alu = {"kernel": g1k["kernel"], "mixed_additions_per_s": g1k["mixed_additions_per_s"],
+           "vmad_peak_per_s": 30.1e12, "frac": g1k["vmad_frac_of_issue_peak"],
+           "alu_only_ceiling_mixed_additions_per_s": 16.7e9,
+           "by_kernel": {x["kernel"]: x["vmad_frac_of_issue_peak"] for x in kerns}}
 
     ms_per_step = elapsed / args.steps * 1e3
     if mode == "single":

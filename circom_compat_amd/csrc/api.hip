@@ -84,14 +84,20 @@ void accumulate_ab(g16_ctx* c, hipStream_t s, StageTimer* tm) {
 // main stream: witness-scalar sort, then the A, B1, L, B2 MSMs (ALU bound).  `after_ab` is called
 // once the A and B1 sums are enqueued: the provers fork the variable-base part of the
 // finalisation onto the side stream there.
-template <class Hook, class Hook2>
-void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 after_b2) {
+void enqueue_witness_sort(g16_ctx* c, const Fr* w_dev) {
   hipStream_t s = c->stream;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
-  ProofSums* S = c->sums_dev.p;
   int id = tm ? tm->begin(ST_MSM_SORT, s) : -1;
   c->sort_w.run(w_dev + 1 + c->w_lo, c->w_hi - c->w_lo, /*mont=*/true, s);
   if (tm) tm->end(id, s);
+}
+
+template <class Hook, class Hook2>
+void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 after_b2, bool sorted = false) {
+  hipStream_t s = c->stream;
+  StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
+  ProofSums* S = c->sums_dev.p;
+  if (!sorted) enqueue_witness_sort(c, w_dev);
   // A/B knobs (measurement only): G16_BATCH_REDUCE / G16_B2_RED_STREAM = 0 | 1 override the size rules
   static const int knob_batch = [] { const char* e = getenv("G16_BATCH_REDUCE"); return e ? atoi(e) : -1; }();
   static const int knob_b2 = [] { const char* e = getenv("G16_B2_RED_STREAM"); return e ? atoi(e) : -1; }();
@@ -287,15 +293,29 @@ void rank_phase1_enqueue(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], 
   G16_HIP(hipStreamWaitEvent(x, c->ev_w, 0));
   c->wd.phase1(w_dev, send_dev, x);
   G16_HIP(hipEventRecord(c->ev_send, x));
-  // the witness-scalar MSMs of this rank's point range run on the main stream during both
-  // exchanges and phases 2-3
-  enqueue_witness_msms(c, w_dev, [&](hipStream_t from) { fork_partial_var(c, from); }, [] {});
+  // The witness-scalar MSMs of this rank run on the main stream during both exchanges and phases
+  // 2-3.  A persistent accumulation grid only hands wave slots to the aux stream when one of its
+  // rounds retires, so phases 2-3 stretch fourfold underneath (profiles/r03_rank8_timeline_*).
+  // G16_MSM_AFTER_PHASE2=1 holds the first accumulation back until phase 2 is through (the sort still
+  // runs now, beside phase 1): the H MSM then never waits for its scalars, but the rank starts
+  // accumulating ~0.4 ms later -- same-box A/B at 2^22 / 8 ranks: 7.98 vs 7.76 ms, at 2^24 equal;
+  // off by default.
+  static const bool defer = [] { const char* e = getenv("G16_MSM_AFTER_PHASE2"); return e && atoi(e) != 0; }();
+  c->msm_deferred = defer;
+  c->w_cur = w_dev;
+  if (defer) enqueue_witness_sort(c, w_dev);
+  else enqueue_witness_msms(c, w_dev, [&](hipStream_t from) { fork_partial_var(c, from); }, [] {});
 }
 
 void rank_phase2_enqueue(g16_ctx* c, const int32_t* recv_dev, int32_t* send_dev) {
   G16_HIP(hipSetDevice(c->device));
   c->wd.phase2(recv_dev, send_dev, c->aux);
   G16_HIP(hipEventRecord(c->ev_send, c->aux));
+  if (c->msm_deferred) {
+    c->msm_deferred = false;
+    G16_HIP(hipStreamWaitEvent(c->stream, c->ev_send, 0));
+    enqueue_witness_msms(c, c->w_cur, [&](hipStream_t from) { fork_partial_var(c, from); }, [] {}, /*sorted=*/true);
+  }
 }
 
 void rank_phase3_enqueue(g16_ctx* c, const int32_t* recv_dev) {
@@ -509,7 +529,16 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     }
 
     // MSM configurations: the four witness queries share one sort, hence one (c, W, planes)
-    const size_t reserve = (size_t)3 << 30;
+    // what is allocated AFTER the planes comes out of the plane budget: sort state (8 + 4 bytes per
+    // entry, two sorts) and the partial-sum workspaces (up to 3 G1 slots + G2 over the witness sort,
+    // one G1 slot over the h sort), sized here with the default windows
+    size_t reserve = (size_t)3 << 30;
+    {
+      const MsmConfig ew = msm_make_config(lw ? lw : 1, o.window_bits, o.planes);
+      const MsmConfig eh = msm_make_config(lh ? lh : 1, o.window_bits, o.planes);
+      reserve += ((size_t)ew.W * lw + (size_t)eh.W * lh) * 12;
+      reserve += ((size_t)ew.nb() + ew.lanes) * (144 * 3 + 288) + ((size_t)eh.nb() + eh.lanes) * 144;
+    }
     g16_ctx* lender = c->share_from;
     // point planes lent by another ctx of the same key on this device (ranks of a multi-device ctx
     // that repeat a device ordinal): same configuration, views of its arrays

@@ -181,7 +181,20 @@ struct FileView {
       n = 0;
       return false;
     }
-    (void)madvise(m, n, MADV_SEQUENTIAL);
+    // No MADV_SEQUENTIAL: the sharded provers read the H section strided (global_index(t)) and a
+    // multi-device ctx uploads every section once per device.  G16_ZKEY_COPY=1 reads the file into
+    // owned memory instead of mapping it: a zkey that is truncated or rewritten while the handle is
+    // open then cannot raise SIGBUS inside a later upload (the mapping requires the file to stay
+    // unchanged until g16_zkey_close; include/g16_loaders.h says so).
+    if (const char* e = getenv("G16_ZKEY_COPY")) {
+      if (e[0] == '1') {
+        own.assign((const uint8_t*)m, (const uint8_t*)m + n);
+        munmap(m, n);
+        p = own.data();
+        return true;
+      }
+    }
+    (void)madvise(m, n, MADV_WILLNEED);
     map = m;
     p = (const uint8_t*)m;
     return true;

@@ -100,7 +100,8 @@ struct MsmSort {
   uint32_t cap = 0, len = 0;
   DevBuf<MsmPair> part;  // level-1 output: (entry, bucket) pairs ordered by partition
   DevBuf<uint32_t> count, offset, cursor, entries, multi_l, meta, scan_tmp;  // meta[1] = #hot buckets
-  DevBuf<uint32_t> gcount1, part_off, cursor1;  // level-1 partition sizes / offsets / cursors
+  DevBuf<uint32_t> part_off;            // level-1 partition offsets (+ total)
+  DevBuf<uint32_t> blk_hist, blk_off;   // [partition][sort block]: per-block counts / their exclusive scan
   // Bucket-range sharding (set_shard, world > 1): every rank walks ALL `n` scalars but keeps only
   // the (bucket, point) pairs of ITS contiguous run of level-1 partitions, chosen on the device from
   // the partition histogram so that the ranks hold equal shares of the sorted entry list (every rank

@@ -7,6 +7,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace g16 {
 
 MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
@@ -150,9 +152,15 @@ __device__ __forceinline__ U256 load_scalar(const void* scalars, uint32_t i) {
   return reinterpret_cast<const U256*>(scalars)[i];
 }
 
+// Level 1, pass A: histogram of the partitions over the tiles of ONE block, stored (not added) at
+// blk_hist[partition][block].  The exclusive scan of that array in this order IS the write position
+// of every (partition, block) run, so pass B needs neither a tile histogram nor a global cursor:
+// the earlier scheme reserved runs with one global atomic per (tile, partition), i.e. ~2000 atomics
+// WITH return on each of <= 1024 addresses, which the L2 serialises (0.3 ms of a 0.34 ms kernel at
+// 2^22 whether a rank kept all digits or an eighth of them).
 template <bool MONT>
 __global__ void __launch_bounds__(P1_THREADS) k_part_count(const void* scalars, uint32_t n,
-                                                           SortGeom G, uint32_t* gcount1) {
+                                                           SortGeom G, uint32_t* blk_hist) {
   __shared__ uint32_t h[P1_MAX_BINS];
   const int tid = threadIdx.x;
   for (uint32_t b = tid; b < G.bins1; b += P1_THREADS) h[b] = 0;
@@ -167,55 +175,70 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_count(const void* scalars, 
     }
   }
   __syncthreads();
-  for (uint32_t b = tid; b < G.bins1; b += P1_THREADS)
-    if (h[b]) atomicAdd(&gcount1[b], h[b]);
+  for (uint32_t b = tid; b < G.bins1; b += P1_THREADS) blk_hist[(size_t)b * gridDim.x + blockIdx.x] = h[b];
+}
+
+// part_off[p] = first position of partition p = blk_off[p][block 0]; part_off[bins1] = total
+__global__ void __launch_bounds__(256) k_part_offsets(const uint32_t* __restrict__ blk_off, uint32_t nblk,
+                                                      uint32_t bins1, uint32_t* part_off) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p <= bins1) part_off[p] = blk_off[(size_t)p * nblk];  // p = bins1: the scan's total
 }
 
 // Cuts the partition-ordered list into `world` contiguous runs of whole partitions with (nearly)
-// equal entry counts and leaves rank's run in range[] (MsmSort::range).  One thread: <= 1024
-// partitions.  Every rank runs this on the same histogram, so the cuts agree without a message.
-// A partition joins the current run when that brings the run closer to its target (the remaining
-// entries over the remaining ranks, so rounding never accumulates); one hot partition larger than a
-// fair share gets a rank to itself.
-__global__ void __launch_bounds__(256) k_pick_range(const uint32_t* part_off, uint32_t bins1, int sh,
-                                                    uint32_t nb, int rank, int world, uint32_t* range) {
-  __shared__ uint32_t off[P1_MAX_BINS + 1];  // staged by the block: the walk below is one lane's serial chain
-  for (uint32_t b = threadIdx.x; b <= bins1; b += blockDim.x) off[b] = part_off[b];
-  __syncthreads();
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const uint32_t M = off[bins1];
-  uint32_t p = 0, lo = 0, hi = 0;
-  for (int g = 0; g <= rank; ++g) {
-    lo = p;
-    if (g == world - 1) {
+// equal entry counts and leaves rank's run in range[] (MsmSort::range).  Every rank runs this on the
+// same histogram, so the cuts agree without a message.  Cut g (the start of rank g's run) is the
+// partition boundary whose prefix count is closest to g M / world -- independent of the other cuts,
+// so each is one binary search (a serial walk over <= 1024 partitions was 0.1 ms of single-lane LDS
+// latency in front of every rank's first accumulation).  A partition larger than a fair share (the
+// value-1 bucket of a 0/1-heavy witness) ends up alone in its run, and a neighbouring run may be empty.
+__global__ void __launch_bounds__(64) k_pick_range(const uint32_t* __restrict__ part_off, uint32_t bins1,
+                                                   int sh, uint32_t nb, int rank, int world,
+                                                   uint32_t* range) {
+  __shared__ uint32_t cut[2];
+  const uint32_t t = threadIdx.x;
+  if (t < 2) {
+    const int g = rank + (int)t;  // t = 0: start of the run, t = 1: its end
+    uint32_t p;
+    if (g <= 0) {
+      p = 0;
+    } else if (g >= world) {
       p = bins1;
     } else {
-      const uint64_t rem = (uint64_t)M - off[p];
-      const uint64_t tgt = rem / (uint64_t)(world - g);
-      uint64_t acc = 0;
-      while (p < bins1) {
-        const uint64_t cnt = (uint64_t)off[p + 1] - off[p];
-        if (acc + cnt / 2 > tgt && !(acc == 0 && cnt != 0 && tgt != 0)) break;
-        acc += cnt;
-        ++p;
+      const uint64_t M = part_off[bins1];
+      const uint64_t tgt = M * (uint64_t)g / (uint64_t)world;
+      uint32_t lo = 0, hi = bins1;  // part_off[lo] <= tgt < part_off[hi] (or lo = hi - 1 at the top)
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (part_off[mid] <= tgt) lo = mid;
+        else hi = mid;
       }
+      // the closer of the two boundaries; ties go down, so equal prefixes (empty partitions) give
+      // every rank the same answer
+      p = (tgt - part_off[lo] <= part_off[hi] - tgt) ? lo : hi;
     }
-    hi = p;
+    cut[t] = p;
   }
+  __syncthreads();
+  if (t != 0) return;
+  const uint32_t lo = cut[0], hi = cut[1] > cut[0] ? cut[1] : cut[0];
   range[0] = lo;
   range[1] = hi;
-  range[2] = off[lo];
-  range[3] = off[hi] - off[lo];
+  range[2] = part_off[lo];
+  range[3] = part_off[hi] - part_off[lo];
   const uint64_t b_lo = (uint64_t)lo << sh, b_hi = (uint64_t)hi << sh;
   range[4] = (uint32_t)(b_lo < nb ? b_lo : nb);
   range[5] = (uint32_t)(b_hi < nb ? b_hi : nb);
 }
 
-// range != nullptr (bucket-range sharding): only the pairs of partitions [range[0], range[1]) are
-// kept, written at their position minus range[2]
+// Level 1, pass B: every block walks the SAME tiles as in pass A; its write cursor of partition p
+// starts at blk_off[p][block] (LDS copy) and a digit's rank is one LDS atomic -- a single digit walk,
+// no global atomics.  range != nullptr (bucket-range sharding): only the pairs of partitions
+// [range[0], range[1]) are kept, written at their position minus range[2].
 template <bool MONT>
 __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars, uint32_t n,
-                                                             SortGeom G, uint32_t* cursor1,
+                                                             SortGeom G,
+                                                             const uint32_t* __restrict__ blk_off,
                                                              MsmPair* part,
                                                              const uint32_t* __restrict__ range) {
   __shared__ uint32_t h[P1_MAX_BINS];
@@ -224,10 +247,9 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
   const uint32_t p_lo = range ? range[0] : 0u, p_hi = range ? range[1] : G.bins1;
   const uint32_t base = range ? range[2] : 0u;
   if (p_lo >= p_hi) return;
+  for (uint32_t b = p_lo + tid; b < p_hi; b += P1_THREADS) h[b] = blk_off[(size_t)b * gridDim.x + blockIdx.x] - base;
+  __syncthreads();
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    for (uint32_t b = tid; b < G.bins1; b += P1_THREADS) h[b] = 0;
-    // the tile's scalars are read (and brought to canonical form) once and stay in registers for
-    // both passes: the tile histogram and the scatter
     U256 sc[P1_PER_THREAD];
     uint32_t idx[P1_PER_THREAD];
     bool live[P1_PER_THREAD];
@@ -238,21 +260,6 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
       if (live[k]) sc[k] = load_scalar<MONT>(scalars, idx[k]);
       else sc[k] = U256{};
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < P1_PER_THREAD; ++k)
-      if (live[k])
-        for_each_digit(sc[k], idx[k], G.c, G.W, G.D, G.B, [&](uint32_t g, uint32_t) {
-          const uint32_t pb = g >> G.sh;
-          if (pb >= p_lo && pb < p_hi) atomicAdd(&h[pb], 1u);
-        });
-    __syncthreads();
-    // reserve this tile's run in every partition; h[] becomes the running write cursor
-    for (uint32_t b = p_lo + tid; b < p_hi; b += P1_THREADS) {
-      const uint32_t cnt = h[b];
-      h[b] = cnt ? atomicAdd(&cursor1[b], cnt) - base : 0u;
-    }
-    __syncthreads();
     // four scalars advance window by window together: their four LDS ranks are issued back to
     // back, then the four stores (one scalar at a time the rank -> store chain is pure latency)
     constexpr int U = 4;
@@ -283,7 +290,6 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
               if (v[u]) part[pos[u]] = MsmPair{e[u], g[u]};
           });
     }
-    __syncthreads();
   }
 }
 
@@ -478,6 +484,16 @@ __global__ void __launch_bounds__(256) k_find_large(const uint32_t* offset, uint
 }  // namespace
 
 
+// workgroups of the sort kernels (G16_SORT_GRID overrides)
+static uint32_t sort_grid_cap() {
+  static const uint32_t cap = [] {
+    const char* e = getenv("G16_SORT_GRID");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 && v <= 8192 ? (uint32_t)v : 2048u;
+  }();
+  return cap;
+}
+
 void MsmSort::set_shard(int rank_, int world_) {
   if (world_ < 1 || rank_ < 0 || rank_ >= world_) throw std::runtime_error("MsmSort::set_shard: bad rank/world");
   rank = rank_;
@@ -493,9 +509,9 @@ void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   const uint64_t M = (uint64_t)cap * cfg.W;
   if (M >= ((uint64_t)1 << 32)) throw std::runtime_error("MSM entry count exceeds 2^32");
   part.alloc(M ? M : 1);
-  gcount1.alloc(P1_MAX_BINS + 1);
   part_off.alloc(P1_MAX_BINS + 1);
-  cursor1.alloc(P1_MAX_BINS + 1);
+  blk_hist.alloc((size_t)P1_MAX_BINS * sort_grid_cap() + 1);
+  blk_off.alloc((size_t)P1_MAX_BINS * sort_grid_cap() + 1);
   count.alloc((size_t)nb + 1);
   offset.alloc((size_t)nb + 1);
   cursor.alloc((size_t)nb + 1);
@@ -503,7 +519,8 @@ void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   // a bucket is 'large' when it spans > MSM_SMALL_MULTI segments of >= MSM_MIN_SEG entries
   multi_l.alloc((size_t)(M / ((uint64_t)MSM_MIN_SEG * MSM_SMALL_MULTI)) + 2);
   meta.alloc(4);
-  scan_tmp.alloc(ceil_div((uint64_t)nb + 1, SCAN_TILE) + 1);
+  const uint64_t scan_len = std::max<uint64_t>((uint64_t)nb + 1, (uint64_t)P1_MAX_BINS * sort_grid_cap() + 1);
+  scan_tmp.alloc(ceil_div(scan_len, SCAN_TILE) + 1);
 }
 
 size_t MsmSort::device_bytes() const {
@@ -523,31 +540,31 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
   G.sh = msm_part_shift(nb);
   G.bins1 = ((nb - 1) >> G.sh) + 1;
   G16_HIP(hipMemsetAsync(count.p, 0, ((size_t)nb + 1) * 4, s));
-  G16_HIP(hipMemsetAsync(gcount1.p, 0, (P1_MAX_BINS + 1) * 4, s));
   G16_HIP(hipMemsetAsync(meta.p, 0, 16, s));
-  static const uint32_t grid_cap = [] {
-    const char* e = getenv("G16_SORT_GRID");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? (uint32_t)v : 2048u;
-  }();
+  const uint32_t grid_cap = sort_grid_cap();
   uint32_t grid1 = ceil_div(n, P1_TILE);
   if (grid1 > grid_cap) grid1 = grid_cap;
   if (grid1 < 1) grid1 = 1;
   uint32_t grid2 = ceil_div((uint64_t)n * cfg.W, P2_CHUNK);
   if (grid2 > grid_cap) grid2 = grid_cap;
   if (grid2 < 1) grid2 = 1;
-  // level 1: partition sizes, then partition
-  if (mont) G16_LAUNCH((k_part_count<true>), grid1, P1_THREADS, 0, s, scalars, n, G, gcount1.p);
-  else G16_LAUNCH((k_part_count<false>), grid1, P1_THREADS, 0, s, scalars, n, G, gcount1.p);
-  scan_exclusive(gcount1.p, G.bins1, 0, part_off.p, cursor1.p, scan_tmp.p, s);
+  // level 1: per-block partition histograms -> scan (= every block's write positions) -> partition
+  const uint32_t L1 = G.bins1 * grid1;
+  if (mont) G16_LAUNCH((k_part_count<true>), grid1, P1_THREADS, 0, s, scalars, n, G, blk_hist.p);
+  else G16_LAUNCH((k_part_count<false>), grid1, P1_THREADS, 0, s, scalars, n, G, blk_hist.p);
+  scan_exclusive(blk_hist.p, L1, 0, blk_off.p, nullptr, scan_tmp.p, s);
+  G16_LAUNCH(k_part_offsets, ceil_div(G.bins1 + 1, 256), 256, 0, s, (const uint32_t*)blk_off.p, grid1,
+             G.bins1, part_off.p);
   const uint32_t* rng = range_dev();
   if (rng)
-    G16_LAUNCH(k_pick_range, 1, 256, 0, s, (const uint32_t*)part_off.p, G.bins1, G.sh, nb, rank, world,
+    G16_LAUNCH(k_pick_range, 1, 64, 0, s, (const uint32_t*)part_off.p, G.bins1, G.sh, nb, rank, world,
                range.p);
   if (mont)
-    G16_LAUNCH((k_part_scatter<true>), grid1, P1_THREADS, 0, s, scalars, n, G, cursor1.p, part.p, rng);
+    G16_LAUNCH((k_part_scatter<true>), grid1, P1_THREADS, 0, s, scalars, n, G, (const uint32_t*)blk_off.p,
+               part.p, rng);
   else
-    G16_LAUNCH((k_part_scatter<false>), grid1, P1_THREADS, 0, s, scalars, n, G, cursor1.p, part.p, rng);
+    G16_LAUNCH((k_part_scatter<false>), grid1, P1_THREADS, 0, s, scalars, n, G, (const uint32_t*)blk_off.p,
+               part.p, rng);
   // level 2: bucket sizes, offsets, final placement (over this rank's pairs only when sharded)
   const uint32_t* total = rng ? rng + 3 : part_off.p + G.bins1;
   G16_LAUNCH(k_bucket_count, grid2, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, count.p);

@@ -35,6 +35,10 @@ typedef struct {                 /* ConstraintMatrices as built by BinFile::matr
   g16_csr a, b;                    /* coefficients Montgomery (file value / R, :322-325) */
 } g16_matrices;
 
+/* g16_zkey_open maps the file (the key arrays handed to g16_ctx_create are views of the page cache):
+ * the file must stay unchanged until g16_zkey_close -- a zkey truncated or rewritten underneath an
+ * open handle faults (SIGBUS) instead of returning G16_ERR_IO.  G16_ZKEY_COPY=1 in the environment
+ * reads it into owned memory instead (the behaviour of g16_zkey_open_mem).                        */
 g16_status g16_zkey_open(const char* path, g16_zkey** out);
 g16_status g16_zkey_open_mem(const uint8_t* data, size_t len, g16_zkey** out); /* data is copied */
 void g16_zkey_close(g16_zkey* z);

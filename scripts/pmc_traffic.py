@@ -6,7 +6,9 @@ requests are counted as 64 B), which sidesteps the FETCH_SIZE calibration caveat
 (FETCH_SIZE = RDREQ x 64 B under-reports 128-byte requests); FETCH_SIZE / WRITE_SIZE (KB) are kept beside it.
 
     python scripts/pmc_traffic.py gpurun_out/pmc22 22 profiles/pmc_traffic.json
-"""
+
+The record is stamped with the sha256 of the library that was loaded (bench.py drops the traffic
+figures when the library it runs on is a different build) and with the date of the passes."""
 import csv
 import glob
 import json
@@ -26,11 +28,14 @@ def traffic(m):
 
 def main(root, log2, out):
     # single-query launches (L, H; every G1 launch when G16_NO_PAIR_AB=1) / the A|B1 pair launch
-    acc, pair = defaultdict(list), defaultdict(list)
+    acc, pair, g2 = defaultdict(list), defaultdict(list), defaultdict(list)
     for path in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
         with open(path) as f:
             for row in csv.DictReader(f):
                 name = row["Kernel_Name"]
+                if "k_bucket_accumulate<g16::Fq2" in name:
+                    g2[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                    continue
                 if "k_bucket_accumulate<g16::Fp<" not in name:
                     continue
                 (pair if "2, true>" in name else acc)[row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -47,6 +52,18 @@ def main(root, log2, out):
         rec.update({"pair_kernel": "k_bucket_accumulate<Fq, 2, true> (A and B1 over interleaved records, one launch)",
                     "pair_read_bytes_per_launch": pr, "pair_write_bytes_per_launch": pw,
                     "pair_traffic_bytes_per_launch": pr + pw, "pair_counters": mp})
+    if g2:
+        mg = {k: sum(v) / len(v) for k, v in g2.items()}
+        gr, gw = traffic(mg)
+        rec.update({"g2_kernel": "k_bucket_accumulate<Fq2, 1, false> (B2 query)",
+                    "g2_read_bytes_per_launch": gr, "g2_write_bytes_per_launch": gw,
+                    "g2_traffic_bytes_per_launch": gr + gw, "g2_counters": mg})
+    import datetime
+    import hashlib
+    lib = os.environ.get("G16_AMD_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                        "circom_compat_amd", "libg16_amd.so")
+    rec["library_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    rec["measured"] = datetime.date.today().isoformat()
     with open(out, "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps({k: rec[k] for k in rec if k.endswith("per_launch") or k.endswith("_kb")}))
