@@ -280,6 +280,33 @@ def solve_r1cs_forward(r1cs, known):
     return w
 
 
+def complex_shape_circuit(cc, num_variables, num_constraints):
+    """the reference bench's circuit family (test-vectors/complex-circuit/complex-circuit.circom.template,
+    swept by benches/groth16.rs:87-104 under feature bench-complex-all): b[0] = a*a, b[i] = b[i-1]^2 for
+    i < NUM_VARIABLES, then NUM_CONSTRAINTS - NUM_VARIABLES repetitions of the last product constraint,
+    c <== b[last] folded into the output wire.  Wire order and signs as circom emits them and as the
+    shipped complex-circuit-10000-10000.r1cs has them: 0 = one, 1 = c, 2 = a, 3.. = b[]; row i is
+    (-x_i) * (x_i) = (-x_{i+1}).  Input a = 3 (input.json)."""
+    V, Cn = int(num_variables), int(num_constraints)
+    assert 1 <= V <= Cn
+    n_vars = V + 2
+    one = cc.fr_from_ints([1])[0]
+    minus1 = cc.fr_from_ints([R_MOD - 1])[0]
+    src = np.concatenate([np.arange(V, dtype=np.uint32), np.full(Cn - V, V - 1, dtype=np.uint32)])  # x_i of row i
+    wire = src + 2
+    cwire = np.where(src + 1 == V, 1, src + 3).astype(np.uint32)                                     # x_{i+1}
+    rp = np.arange(Cn + 1, dtype=np.uint32)
+    A = cc.Csr(rp, wire, np.tile(minus1, (Cn, 1)))
+    B = cc.Csr(rp, wire, np.tile(one, (Cn, 1)))
+    Cm = cc.Csr(rp, cwire, np.tile(minus1, (Cn, 1)))
+    xs = [3]
+    for _ in range(V):
+        xs.append(xs[-1] * xs[-1] % R_MOD)
+    w = [1, xs[V]] + xs[:V]
+    mats = cc.ConstraintMatrices(2, n_vars - 1, Cn, A, B)
+    return mats, (A, B, Cm), w, n_vars
+
+
 def complex_circuit(cc):
     """the reference bench's default circuit (benches/groth16.rs:87-108), input a = 3"""
     r1cs = cc.R1CS.from_file(os.path.join(ROOT, "tests", "golden", "complex-circuit-10000-10000.r1cs"))

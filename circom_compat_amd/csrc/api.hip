@@ -364,7 +364,13 @@ const char* g16_last_error(const g16_ctx* ctx) {
 
 namespace g16 {
 
+// AUTO: bucket ranges when the planes fit AND the domain is at most 2^22.  Measured on one MI355X,
+// one rank of 8 alone (scripts/dist_projection.py, profiles/r03_proj_*): the two cuts tie at 2^22
+// (7.6 ms per rank either way) and point ranges win at 2^24 (20.7 vs 21.3 ms) -- every bucket-sharded
+// rank walks ALL n scalars to keep an eighth of the digits, and that front (2.3 ms at 2^24) costs
+// more than the window it saves (W = 12 instead of 13: -1.0 ms of accumulation).  DESIGN.md section 7.
 bool bucket_shard_fits(int device, uint32_t n_vars, uint32_t domain, const g16_options* opt) {
+  if (domain > (1u << 22)) return false;
   if (hipSetDevice(device) != hipSuccess) return false;
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;

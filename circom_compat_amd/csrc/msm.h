@@ -44,11 +44,21 @@ struct MsmConfig {
   uint32_t nb() const { return (uint32_t)D * B; }
 };
 
-// level-1 partition of the counting sort = bucket >> msm_part_shift(nb): at most 1024 partitions
+// level-1 partition of the counting sort = bucket >> msm_part_shift(nb): at most 2^msm_part_bits()
+// partitions (G16_SORT_BINS = 6..10 overrides; every (sort block, partition) pair is one write
+// stream of the level-1 scatter, level 2 needs a partition to span <= 2048 buckets ... 4096 per chunk)
+inline int msm_part_bits() {
+  static const int bits = [] {
+    const char* e = getenv("G16_SORT_BINS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 6 && v <= 10 ? v : 10;
+  }();
+  return bits;
+}
 inline int msm_part_shift(uint32_t nb) {
   int bits = 0;
   while (((uint64_t)1 << bits) < nb) ++bits;
-  return bits > 10 ? bits - 10 : 0;
+  return bits > msm_part_bits() ? bits - msm_part_bits() : 0;
 }
 
 // buckets per thread of k_bucket_reduce.  The kernel is a serial chain of ~3 EC additions per bucket

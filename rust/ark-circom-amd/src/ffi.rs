@@ -16,6 +16,9 @@ pub const G16_ERR_INTERNAL: g16_status = 6;
 pub const G16_PROOF_BYTES: usize = 256;
 pub const G16_PARTIAL_BYTES: usize = 1024;
 pub const G16_N_STAGES: usize = 7;
+pub const G16_SHARD_AUTO: c_int = 0;
+pub const G16_SHARD_POINTS: c_int = 1;
+pub const G16_SHARD_BUCKETS: c_int = 2;
 pub const G16_REDUCTION_CIRCOM: c_int = 0;
 pub const G16_REDUCTION_LIBSNARK: c_int = 1;
 pub const G16_QUERY_A: c_int = 0;
@@ -77,7 +80,8 @@ pub struct g16_options {
     pub planes: c_int,
     pub dist_wm: c_int,
     pub reduction: c_int,
-    pub reserved: [c_int; 1],
+    /// world > 1 / multi-device: G16_SHARD_AUTO, G16_SHARD_POINTS or G16_SHARD_BUCKETS
+    pub shard: c_int,
 }
 
 #[repr(C)]

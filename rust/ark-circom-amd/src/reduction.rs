@@ -2,8 +2,11 @@
 //! reference src/circom/qap.rs:14-106) whose `witness_map_from_matrices` runs on the GPU.
 //!
 //! The trait is stateless (static methods, no `self`), so the resident state lives in a
-//! thread-local cache keyed by the matrices' address and shape: the first call uploads A and B,
-//! later calls with the same `&ConstraintMatrices` only upload the witness.  The MSMs inside
+//! thread-local cache keyed by the matrices' CONTENT (shape + a 64-bit FNV-1a hash over every row's
+//! coefficients and indices; an address would be reused by a freed-and-reallocated `Vec` of the
+//! same shape and silently pair a stale device ctx with new matrices): the first call uploads A
+//! and B, later calls with equal matrices only upload the witness.  Hashing is one pass over nnz
+//! (coefficient, index) pairs -- cheaper than the pack + upload it saves.  The MSMs inside
 //! `ark_groth16` are not overridable through this trait -- use `GpuProver` / `Groth16Gpu` for the
 //! whole proof; this impl exists for callers that only want `h`.
 use std::any::TypeId;
@@ -22,7 +25,7 @@ use crate::pack::{self, Csr};
 pub struct GpuCircomReduction;
 
 struct WmCtx {
-    key: (usize, usize, usize, usize), // (&matrices.a as ptr, num_constraints, num_inputs, n_vars)
+    key: (u64, usize, usize, usize), // (content hash of A and B, num_constraints, num_inputs, n_vars)
     ctx: *mut ffi::g16_ctx,
     domain_size: usize,
 }
@@ -35,13 +38,37 @@ thread_local! {
     static CACHE: RefCell<Option<WmCtx>> = RefCell::new(None);
 }
 
+/// FNV-1a over the rows of A and B: row lengths, wire indices and the coefficients' limbs
+fn content_hash(m: &ConstraintMatrices<Fr>) -> u64 {
+    let mut h: u64 = 0xcbf29ce484222325;
+    let mut eat = |x: u64| {
+        for b in x.to_le_bytes() {
+            h ^= b as u64;
+            h = h.wrapping_mul(0x100000001b3);
+        }
+    };
+    for mat in [&m.a, &m.b] {
+        eat(mat.len() as u64);
+        for row in mat.iter() {
+            eat(row.len() as u64);
+            for (coeff, idx) in row.iter() {
+                eat(*idx as u64);
+                for limb in coeff.into_bigint().0 {
+                    eat(limb);
+                }
+            }
+        }
+    }
+    h
+}
+
 fn gpu_witness_map(
     matrices: &ConstraintMatrices<Fr>,
     num_inputs: usize,
     num_constraints: usize,
     full_assignment: &[Fr],
 ) -> Result<Vec<Fr>, SynthesisError> {
-    let key = (matrices.a.as_ptr() as usize, num_constraints, num_inputs, full_assignment.len());
+    let key = (content_hash(matrices), num_constraints, num_inputs, full_assignment.len());
     CACHE.with(|cell| {
         let mut slot = cell.borrow_mut();
         if slot.as_ref().map(|c| c.key) != Some(key) {
