@@ -364,13 +364,9 @@ const char* g16_last_error(const g16_ctx* ctx) {
 
 namespace g16 {
 
-// AUTO: bucket ranges when the planes fit AND the domain is at most 2^22.  Measured on one MI355X,
-// one rank of 8 alone (scripts/dist_projection.py, profiles/r03_proj_*): the two cuts tie at 2^22
-// (7.6 ms per rank either way) and point ranges win at 2^24 (20.7 vs 21.3 ms) -- every bucket-sharded
-// rank walks ALL n scalars to keep an eighth of the digits, and that front (2.3 ms at 2^24) costs
-// more than the window it saves (W = 12 instead of 13: -1.0 ms of accumulation).  DESIGN.md section 7.
+// Do the full planes of the four witness queries (+ H, counted whole as an upper bound) fit `device`?
+// Asked before a bucket-sharded ctx is built (G16_SHARD_BUCKETS), so that the refusal names the reason.
 bool bucket_shard_fits(int device, uint32_t n_vars, uint32_t domain, const g16_options* opt) {
-  if (domain > (1u << 22)) return false;
   if (hipSetDevice(device) != hipSuccess) return false;
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
@@ -381,7 +377,7 @@ bool bucket_shard_fits(int device, uint32_t n_vars, uint32_t domain, const g16_o
   // bytes per entry) + work buffers, against 70 % of what is free beyond 3 GiB
   const size_t planes = (size_t)cw.Pn * len_w * (64 * 3 + 128) + (size_t)ch.Pn * domain * 64;
   const size_t sorts = ((size_t)cw.W * len_w + (size_t)ch.W * domain) * 12;
-  const size_t work = ((size_t)cw.nb() + cw.lanes) * (144 * 3 + 288) + ((size_t)ch.nb() + ch.lanes) * 144;
+  const size_t work = ((size_t)cw.nb() + cw.max_lanes()) * (144 * 3 + 288) + ((size_t)ch.nb() + ch.max_lanes()) * 144;
   const size_t reserve = (size_t)3 << 30;
   return fr > reserve && planes + sorts + work < (size_t)((fr - reserve) * 0.7);
 }
@@ -492,9 +488,14 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
 
     const uint32_t len_w = c->N - 1;
     c->has_key = key->a_query != nullptr;
-    c->shard_buckets = (c->world > 1 || c->dist_wm) && c->has_key &&
-                       (o.shard == G16_SHARD_BUCKETS ||
-                        (o.shard == G16_SHARD_AUTO && (share_from || bucket_shard_fits(c->device, c->N, c->n, &o))));
+    // AUTO = point ranges.  Measured on one MI355X, one rank of 8 alone (scripts/dist_projection.py,
+    // profiles/r03_proj_k22.json / _k24.json): the two cuts tie -- 7.6 / 7.8 ms per rank at 2^22, 21.0 /
+    // 21.4 ms at 2^24 -- because a bucket-sharded rank walks ALL n scalars to keep an eighth of the
+    // digits and that front costs what the single-GPU window saves; point ranges need 1/world of the
+    // key per device instead of all of it.  DESIGN.md section 7.
+    c->shard_buckets = (c->world > 1 || c->dist_wm) && c->has_key && o.shard == G16_SHARD_BUCKETS;
+    if (c->shard_buckets && !share_from && !bucket_shard_fits(c->device, c->N, c->n, &o))
+      throw std::runtime_error("G16_SHARD_BUCKETS: the full point planes of the witness queries do not fit this device");
     c->share_from = c->shard_buckets ? share_from : nullptr;
     // the H query is ALWAYS cut by point range: its scalars are born sharded (the distributed
     // witness map leaves rank g the n / world evaluations e = global_index(t)), so every rank
@@ -543,7 +544,7 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       const MsmConfig ew = msm_make_config(lw ? lw : 1, o.window_bits, o.planes);
       const MsmConfig eh = msm_make_config(lh ? lh : 1, o.window_bits, o.planes);
       reserve += ((size_t)ew.W * lw + (size_t)eh.W * lh) * 12;
-      reserve += ((size_t)ew.nb() + ew.lanes) * (144 * 3 + 288) + ((size_t)eh.nb() + eh.lanes) * 144;
+      reserve += ((size_t)ew.nb() + ew.max_lanes()) * (144 * 3 + 288) + ((size_t)eh.nb() + eh.max_lanes()) * 144;
     }
     g16_ctx* lender = c->share_from;
     // point planes lent by another ctx of the same key on this device (ranks of a multi-device ctx
@@ -603,7 +604,7 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     {
       const uint32_t nc_w = ceil_div(c->cfg_w.B, msm_red_chunk(c->cfg_w, 1, wr)) * c->cfg_w.D;
       const uint32_t nc_h = ceil_div(c->cfg_h.B, msm_red_chunk(c->cfg_h)) * c->cfg_h.D;
-      const uint32_t slots_w = c->cfg_w.nb() + c->cfg_w.lanes, slots_h = c->cfg_h.nb() + c->cfg_h.lanes;
+      const uint32_t slots_w = c->cfg_w.nb() + c->cfg_w.max_lanes(), slots_h = c->cfg_h.nb() + c->cfg_h.max_lanes();
       c->work1.init(slots_w, nc_w, c->cfg_w.D, /*batch=*/(c->cfg_w.nb() / wr < (1u << 18) || wr > 1 || getenv("G16_BATCH_REDUCE")) ? 3 : 2);
       c->workH.init(slots_h, nc_h, c->cfg_h.D, 1);
       c->work2.init(slots_w, nc_w, c->cfg_w.D);

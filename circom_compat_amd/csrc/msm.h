@@ -27,7 +27,9 @@
 namespace g16 {
 
 constexpr int MSM_ACC_THREADS = 128;    // workgroup of the accumulation kernel
-constexpr int MSM_ACC_BLOCKS = 2048;    // segments = 2048 x 128: two rounds of 2 waves per SIMD on 256 CUs (G16_ACC_GRID overrides)
+constexpr int MSM_ACC_BLOCKS = 3072;    // G1: segments = 3072 x 128 -- two rounds of the optimistic kernel's 3 waves per SIMD on 256 CUs (G16_ACC_GRID overrides)
+constexpr int MSM_ACC_BLOCKS_G2 = 2048; // G2: 2048 x 128 (one wave per SIMD, four rounds; G16_ACC_GRID_G2 overrides).  Same box, 2^22,
+                                        // ms per launch at 2048 / 3072 workgroups: A|B1 pair 9.69 / 9.38, L or H 4.73 / 4.49, B2 12.1 / 12.8
 constexpr int MSM_MIN_SEG = 8;          // shortest per-lane segment
 constexpr int MSM_SMALL_MULTI = 32;     // buckets with <= this many partials are summed inside the reduce
 constexpr int MSM_RED_CHUNK = 16;   // max buckets per thread in the weighted bucket reduction
@@ -40,8 +42,10 @@ struct MsmConfig {
   int Pn = 1;      // stored multiples (planes) per point
   int D = 0;       // bucket sets = ceil(W / Pn)
   uint32_t B = 0;  // buckets per set = 2^(c-1)
-  uint32_t lanes = MSM_ACC_BLOCKS * MSM_ACC_THREADS;  // segments the entry list is cut into
+  uint32_t lanes = MSM_ACC_BLOCKS * MSM_ACC_THREADS;        // segments the entry list is cut into by the G1 launches
+  uint32_t lanes2 = MSM_ACC_BLOCKS_G2 * MSM_ACC_THREADS;    // ... by the G2 launch over the same sort
   uint32_t nb() const { return (uint32_t)D * B; }
+  uint32_t max_lanes() const { return lanes > lanes2 ? lanes : lanes2; }
 };
 
 // level-1 partition of the counting sort = bucket >> msm_part_shift(nb): at most 2^msm_part_bits()
@@ -109,7 +113,11 @@ struct MsmSort {
   MsmConfig cfg;
   uint32_t cap = 0, len = 0;
   DevBuf<MsmPair> part;  // level-1 output: (entry, bucket) pairs ordered by partition
-  DevBuf<uint32_t> count, offset, cursor, entries, multi_l, meta, scan_tmp;  // meta[1] = #hot buckets
+  // multi_l / meta: hot buckets of the G1 segmentation (cfg.lanes), multi_l2 / meta2: of the G2 one; meta[1] = their number
+  DevBuf<uint32_t> count, offset, cursor, entries, multi_l, meta, multi_l2, meta2, scan_tmp;
+  uint32_t lanes_of(bool g2) const { return g2 ? cfg.lanes2 : cfg.lanes; }
+  const uint32_t* large_list(bool g2) const { return g2 ? multi_l2.p : multi_l.p; }
+  const uint32_t* large_meta(bool g2) const { return g2 ? meta2.p : meta.p; }
   DevBuf<uint32_t> part_off;            // level-1 partition offsets (+ total)
   DevBuf<uint32_t> blk_hist, blk_off;   // [partition][sort block]: per-block counts / their exclusive scan
   // Bucket-range sharding (set_shard, world > 1): every rank walks ALL `n` scalars but keeps only
@@ -155,6 +163,17 @@ struct MsmPoints {
                         hipStream_t stream);
 };
 
+// Mixed additions the optimistic accumulation kernel set aside (its x-coordinate filter fired:
+// acc = +-P is possible): (slot of the partial sum the addition belongs to, sort entry).  A list that
+// overflows marks the launch for the exact kernel.
+constexpr uint32_t MSM_FIX_CAP = 512;
+struct MsmFixList {
+  uint32_t count;     // appended by k_bucket_accumulate<.., FAST>, reset by k_acc_fixup
+  uint32_t overflow;  // written by k_acc_fixup: the exact kernel behind it redoes the whole launch
+  uint32_t slot[MSM_FIX_CAP];  // bit 31: second half of an interleaved pair
+  uint32_t entry[MSM_FIX_CAP];
+};
+
 template <class F>
 struct MsmWork {
   int batch = 1;                    // MSMs whose partials can be alive at once (workspace slots)
@@ -164,6 +183,7 @@ struct MsmWork {
   DevBuf<MsmAcc<F>> contrib;  // [batch][ncontrib]: one per reduction chunk
   DevBuf<MsmAcc<F>> bsum;     // [batch][256 * sets]: intermediate tree level
   DevBuf<MsmAcc<F>> wsum;     // [batch][sets]: one per bucket set
+  DevBuf<MsmFixList> fix;     // deferred exact additions of the G1 accumulation launch in flight
   // sized for the larger of several sorts that will share this workspace
   void init(uint32_t n_slots, uint32_t n_contrib, int max_sets, int batch = 1);
 };

@@ -20,6 +20,12 @@ namespace g16 {
 namespace {
 
 constexpr int ACC_THREADS = MSM_ACC_THREADS;
+
+// G16_ACC_FAST=0: the exact in-kernel redo only (A/B partner of the optimistic G1 kernel)
+inline bool acc_fast() {
+  static const bool v = [] { const char* e = getenv("G16_ACC_FAST"); return !e || atoi(e) != 0; }();
+  return v;
+}
 constexpr int COMB_THREADS = 64;
 constexpr int SUM_THREADS = 128;
 
@@ -148,12 +154,29 @@ __device__ __forceinline__ Aff29<typename Lazy<F>::type> acc_way_prepare(
   return p;
 }
 
-template <class F>
+// FAST: the rare addition whose x-coordinates may coincide (2^-23 filter; true coincidences need
+// repeated points) is not redone here -- an exact madd() drags an out-of-line call, its scratch frame
+// and ~90 VGPRs into the hot kernel -- but appended to a list: (slot of the partial this accumulator
+// will be stored to, entry).  k_acc_fixup adds the listed points to the stored partials afterwards.
+template <class F, bool FAST>
 __device__ __forceinline__ void acc_way_commit(AccWay<F>& w, bool step,
                                                const XYZZ29<typename Lazy<F>::type>& res, bool special,
-                                               const Aff29<typename Lazy<F>::type>& p) {
-  if (special) w.acc.madd(p);  // x-coordinates may coincide: redo exactly (doubling / cancellation)
-  else w.acc = res;
+                                               const Aff29<typename Lazy<F>::type>& p, uint32_t en,
+                                               uint32_t half, MsmFixList* fix) {
+  if (FAST) {
+    if (special) {
+      const uint32_t k = atomicAdd(&fix->count, 1u);
+      if (k < MSM_FIX_CAP) {
+        fix->slot[k] = (w.g + w.seg) | (half << 31);
+        fix->entry[k] = en;
+      }
+    } else {
+      w.acc = res;
+    }
+  } else {
+    if (special) w.acc.madd(p);  // x-coordinates may coincide: redo exactly (doubling / cancellation)
+    else w.acc = res;
+  }
   if (step) ++w.pos;
 }
 
@@ -168,18 +191,22 @@ __device__ __forceinline__ void acc_way_commit(AccWay<F>& w, bool step,
 // MsmPoints::init_pair).  PAIR: both halves in one launch -- the two waves of a workgroup walk the SAME 64 segments, wave h over half h
 // of every 128-byte record into partial set h -- identical control flow, so the waves stay within an
 // iteration or two of each other and the later one finds the line in the cache.
-template <class F, int PS, bool PAIR>
+// FAST (G1): optimistic kernel, see acc_way_commit; !FAST with a list: the exact kernel launched
+// behind it, which returns at once unless the list overflowed (fix->overflow, set by k_acc_fixup).
+template <class F, int PS, bool PAIR, bool FAST>
 __global__ void __launch_bounds__(ACC_THREADS)
     k_bucket_accumulate(const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min,
                         const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset,
                         uint32_t nb, uint32_t lanes, MsmAcc<F>* __restrict__ partial,
-                        size_t slot_stride) {
+                        size_t slot_stride, MsmFixList* fix) {
   using LF = typename Lazy<F>::type;
+  if (!FAST && fix && fix->overflow == 0) return;
   const uint32_t M = offset[nb];
   const uint32_t S = msm_seg_len(M, lanes);
   uint32_t nthreads = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t half = 0;
   if (PAIR) {
-    const uint32_t half = threadIdx.x / (ACC_THREADS / 2);
+    half = threadIdx.x / (ACC_THREADS / 2);
     pts += half;
     partial += (size_t)half * slot_stride;
     nthreads /= 2;
@@ -191,12 +218,67 @@ __global__ void __launch_bounds__(ACC_THREADS)
     if (!w.live) break;  // segments are handed out in order: nothing left for later threads either
     for (uint32_t it = 0; it < S; ++it) {
       bool step, special;
+      const uint32_t en = w.en_next;  // the entry whose point acc_way_prepare unpacks
       const Aff29<LF> p =
           acc_way_prepare<F, PS>(w, &step, pts, npts, idx_min, entries, offset, nb, partial);
       const XYZZ29<LF> r = XYZZ29<LF>::madd_select(w.acc, p, &special);
-      acc_way_commit<F>(w, step, r, special, p);
+      acc_way_commit<F, FAST>(w, step, r, special, p, en, half, fix);
     }
     partial[w.g + w.seg] = w.acc;
+  }
+}
+
+// Adds the deferred points (MsmFixList) to their stored partials with the exact madd().  One block;
+// items that share a slot are taken one per round (the list is short: ~6 false positives of the
+// filter per 2^22 MSM).  An overflowed list is left to the exact kernel: overflow = 1.
+template <class F, int PS>
+__global__ void __launch_bounds__(256)
+    k_acc_fixup(const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min, MsmFixList* fix,
+                MsmAcc<F>* partial, size_t slot_stride) {
+  __shared__ uint32_t sl[MSM_FIX_CAP];
+  __shared__ uint32_t done[MSM_FIX_CAP];
+  __shared__ uint32_t left;
+  const uint32_t n = fix->count;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fix->overflow = n > MSM_FIX_CAP ? 1u : 0u;
+    fix->count = 0;
+  }
+  if (n == 0 || n > MSM_FIX_CAP) return;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    sl[i] = fix->slot[i];
+    done[i] = 0;
+  }
+  if (threadIdx.x == 0) left = n;
+  __syncthreads();
+  while (left != 0) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+      if (done[i]) continue;
+      bool first = true;  // no earlier pending item on the same slot
+      for (uint32_t j = 0; j < i; ++j)
+        if (done[j] != 1 && sl[j] == sl[i]) first = false;  // 0: pending, 2: being added in this round
+      if (!first) continue;
+      const uint32_t en = fix->entry[i], half = sl[i] >> 31, slot = sl[i] & 0x7fffffffu;
+      Affine<F> raw;
+      acc_fetch<F, PS>(pts + half, npts, idx_min, en, raw);
+      Aff29<typename Lazy<F>::type> p = load_packed_affine<F>(raw);
+      if (en >> 31) p.y = p.y.neg().carry();
+      MsmAcc<F>* dst = partial + (size_t)half * slot_stride + slot;
+      MsmAcc<F> a = *dst;
+      a.madd(p);
+      *dst = a;
+      done[i] = 2;  // finished in this round
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t l = 0;
+      for (uint32_t i = 0; i < n; ++i) {
+        if (done[i] == 2) done[i] = 1;
+        if (!done[i]) ++l;
+      }
+      left = l;
+    }
+    __syncthreads();
   }
 }
 
@@ -449,6 +531,8 @@ void MsmWork<F>::init(uint32_t n_slots, uint32_t n_contrib, int max_sets, int ba
   contrib.alloc((size_t)batch * ncontrib);
   bsum.alloc((size_t)batch * 256 * sets);
   wsum.alloc((size_t)batch * sets);
+  fix.alloc(1);
+  G16_HIP(hipMemset(fix.p, 0, sizeof(MsmFixList)));
 }
 
 template <class F>
@@ -458,8 +542,9 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
   const uint32_t nb = cfg.nb();
   const int acc_stage = sizeof(F) == sizeof(Fq) ? ST_MSM_ACC_G1 : ST_MSM_ACC_G2;
   if (slot < 0 || slot >= work.batch) throw std::runtime_error("msm_accumulate: bad workspace slot");
-  // persistent grid: cfg.lanes lanes, each owning an equal segment of the sorted entry list
-  const uint32_t grid = cfg.lanes / ACC_THREADS;
+  // persistent grid: `lanes` lanes, each owning an equal segment of the sorted entry list
+  const uint32_t lanes = s.lanes_of(sizeof(F) != sizeof(Fq));
+  const uint32_t grid = lanes / ACC_THREADS;
 #ifdef G16_DEBUG_GATHER
   static const bool mask_set = [] {
     if (const char* e = getenv("G16_DEBUG_GATHER_MASK")) {
@@ -472,14 +557,35 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
 #endif
   int id = tm ? tm->begin(acc_stage, stream) : -1;
   MsmAcc<F>* out = work.partial.p + (size_t)slot * work.slots;
+  const uint32_t* en = (const uint32_t*)s.entries.p;
+  const uint32_t* of = (const uint32_t*)s.offset.p;
+  if constexpr (sizeof(F) == sizeof(Fq)) {
+    if (acc_fast()) {
+      // optimistic kernel, deferred exact additions, exact kernel (returns at once unless the list overflowed)
+      MsmFixList* fix = work.fix.p;
+      if (P.stride == 2) {
+        G16_LAUNCH((k_bucket_accumulate<F, 2, false, true>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
+                   P.count, idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+        G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, P.data() + P.off, P.count, idx_min, fix, out, (size_t)0);
+        G16_LAUNCH((k_bucket_accumulate<F, 2, false, false>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
+                   P.count, idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+      } else {
+        G16_LAUNCH((k_bucket_accumulate<F, 1, false, true>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
+                   idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+        G16_LAUNCH((k_acc_fixup<F, 1>), 1, 256, 0, stream, P.data(), P.count, idx_min, fix, out, (size_t)0);
+        G16_LAUNCH((k_bucket_accumulate<F, 1, false, false>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
+                   idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+      }
+      if (tm) tm->end(id, stream);
+      return;
+    }
+  }
   if (P.stride == 2)
-    G16_LAUNCH((k_bucket_accumulate<F, 2, false>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
-               P.count, idx_min, (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb,
-               cfg.lanes, out, (size_t)0);
+    G16_LAUNCH((k_bucket_accumulate<F, 2, false, false>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
+               P.count, idx_min, en, of, nb, lanes, out, (size_t)0, (MsmFixList*)nullptr);
   else
-    G16_LAUNCH((k_bucket_accumulate<F, 1, false>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
-               idx_min, (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb, cfg.lanes, out,
-               (size_t)0);
+    G16_LAUNCH((k_bucket_accumulate<F, 1, false, false>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
+               idx_min, en, of, nb, lanes, out, (size_t)0, (MsmFixList*)nullptr);
   if (tm) tm->end(id, stream);
 }
 
@@ -496,9 +602,23 @@ void msm_accumulate_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoint
   // twice the workgroups of a single launch: each one covers 64 segments with both of its waves
   const uint32_t grid = cfg.lanes / (ACC_THREADS / 2);
   int id = tm ? tm->begin(acc_stage, stream) : -1;
-  G16_LAUNCH((k_bucket_accumulate<F, 2, true>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
-             (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb, cfg.lanes,
-             work.partial.p + (size_t)slot * work.slots, (size_t)work.slots);
+  const uint32_t* en = (const uint32_t*)s.entries.p;
+  const uint32_t* of = (const uint32_t*)s.offset.p;
+  MsmAcc<F>* out = work.partial.p + (size_t)slot * work.slots;
+  if constexpr (sizeof(F) == sizeof(Fq)) {
+    if (acc_fast()) {
+      MsmFixList* fix = work.fix.p;
+      G16_LAUNCH((k_bucket_accumulate<F, 2, true, true>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
+                 en, of, nb, cfg.lanes, out, (size_t)work.slots, fix);
+      G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, A.data(), A.count, 0u, fix, out, (size_t)work.slots);
+      G16_LAUNCH((k_bucket_accumulate<F, 2, true, false>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
+                 en, of, nb, cfg.lanes, out, (size_t)work.slots, fix);
+      if (tm) tm->end(id, stream);
+      return;
+    }
+  }
+  G16_LAUNCH((k_bucket_accumulate<F, 2, true, false>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
+             en, of, nb, cfg.lanes, out, (size_t)work.slots, (MsmFixList*)nullptr);
   if (tm) tm->end(id, stream);
 }
 
@@ -514,9 +634,11 @@ void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, 
     throw std::runtime_error("msm_reduce: bad workspace slots");
   MsmAcc<F>* partial = work.partial.p + (size_t)first_slot * work.slots;
   int id = tm ? tm->begin(ST_MSM_REDUCE, stream) : -1;
+  const bool g2 = sizeof(F) != sizeof(Fq);
+  const uint32_t lanes = s.lanes_of(g2);
   G16_LAUNCH((k_combine_large<F>), dim3(1024, nbatch), COMB_THREADS, COMB_THREADS * sizeof(MsmAcc<F>),
-             stream, (const uint32_t*)s.multi_l.p, (const uint32_t*)s.meta.p,
-             (const uint32_t*)s.offset.p, nb, cfg.lanes, partial, (size_t)work.slots);
+             stream, s.large_list(g2), s.large_meta(g2),
+             (const uint32_t*)s.offset.p, nb, lanes, partial, (size_t)work.slots);
   // buckets per thread: the running sums are a dependent chain of EC additions (~10 us each on
   // one lane): see msm_red_chunk for the thread count this aims at
   const uint32_t* rng = s.range_dev();  // bucket-range sharding: this rank's run of the bucket set
@@ -525,7 +647,7 @@ void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, 
   const uint32_t nchunks = cps * (uint32_t)cfg.D;
   if (nchunks > work.ncontrib) throw std::runtime_error("msm_reduce: contribution buffer too small");
   G16_LAUNCH((k_bucket_reduce<F>), dim3(ceil_div(nchunks, 64), nbatch), 64, 0, stream,
-             (const MsmAcc<F>*)partial, (const uint32_t*)s.offset.p, nb, cfg.lanes, cfg.B, red_chunk,
+             (const MsmAcc<F>*)partial, (const uint32_t*)s.offset.p, nb, lanes, cfg.B, red_chunk,
              cps, nchunks, work.contrib.p, (size_t)work.slots, rng);
   // two-level tree: cps contributions -> nblk block sums -> 1 per set
   uint32_t nblk = ceil_div(cps / (uint32_t)s.world, SUM_THREADS * 2);

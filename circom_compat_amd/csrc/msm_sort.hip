@@ -54,6 +54,10 @@ MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
     const int v = atoi(e);
     if (v >= 1 && v <= 65536) cfg.lanes = (uint32_t)v * MSM_ACC_THREADS;
   }
+  if (const char* e = getenv("G16_ACC_GRID_G2")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 65536) cfg.lanes2 = (uint32_t)v * MSM_ACC_THREADS;
+  }
   return cfg;
 }
 
@@ -519,6 +523,8 @@ void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   // a bucket is 'large' when it spans > MSM_SMALL_MULTI segments of >= MSM_MIN_SEG entries
   multi_l.alloc((size_t)(M / ((uint64_t)MSM_MIN_SEG * MSM_SMALL_MULTI)) + 2);
   meta.alloc(4);
+  multi_l2.alloc((size_t)(M / ((uint64_t)MSM_MIN_SEG * MSM_SMALL_MULTI)) + 2);
+  meta2.alloc(4);
   const uint64_t scan_len = std::max<uint64_t>((uint64_t)nb + 1, (uint64_t)P1_MAX_BINS * sort_grid_cap() + 1);
   scan_tmp.alloc(ceil_div(scan_len, SCAN_TILE) + 1);
 }
@@ -541,6 +547,7 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
   G.bins1 = ((nb - 1) >> G.sh) + 1;
   G16_HIP(hipMemsetAsync(count.p, 0, ((size_t)nb + 1) * 4, s));
   G16_HIP(hipMemsetAsync(meta.p, 0, 16, s));
+  G16_HIP(hipMemsetAsync(meta2.p, 0, 16, s));
   const uint32_t grid_cap = sort_grid_cap();
   uint32_t grid1 = ceil_div(n, P1_TILE);
   if (grid1 > grid_cap) grid1 = grid_cap;
@@ -576,6 +583,8 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
              entries.p);
   G16_LAUNCH(k_find_large, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)offset.p, nb, cfg.lanes,
              multi_l.p, meta.p);
+  G16_LAUNCH(k_find_large, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)offset.p, nb, cfg.lanes2,
+             multi_l2.p, meta2.p);
 }
 
 }  // namespace g16

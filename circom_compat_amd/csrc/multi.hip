@@ -296,11 +296,9 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
   const bool libsnark = opt && opt->reduction == G16_REDUCTION_LIBSNARK;
   M->dist = is_pow2(n_dev) && n_dev > 1 && !libsnark && (1u << (k / 2)) >= (uint32_t)n_dev &&
             !(opt && opt->dist_wm < 0);
-  // bucket-range sharding when asked for, or (AUTO) when the full planes of the whole key fit one
-  // device; point ranges otherwise
-  const int want = opt ? opt->shard : G16_SHARD_AUTO;
-  M->buckets = want == G16_SHARD_BUCKETS ||
-               (want == G16_SHARD_AUTO && bucket_shard_fits(device_ids[0], key->n_vars, key->domain_size, opt));
+  // bucket-range sharding of the witness-scalar MSMs when asked for; AUTO = point ranges (the two
+  // cuts tie in rank time, point ranges hold 1/n_dev of the key per device: api.hip)
+  M->buckets = opt && opt->shard == G16_SHARD_BUCKETS;
   M->pool.start(n_dev);
   // ranks that repeat a device ordinal (functional runs of an N-rank prover on fewer GPUs) borrow
   // the point planes of the first rank on that device under bucket-range sharding, where every

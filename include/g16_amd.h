@@ -88,7 +88,11 @@ typedef struct {
  *            traffic is the 1 KiB record per rank.  The H query stays cut by point range -- its
  *            scalars are born sharded (the distributed witness map leaves rank g its n / world
  *            evaluations), moving them would put the whole vector on every link.
- *   AUTO     BUCKETS when the full planes of the witness queries fit the device, else POINTS.      */
+ *   AUTO     POINTS.  One rank of 8 measured alone on an MI355X takes the same time either way
+ *            (7.6 / 7.8 ms at 2^22, 21.0 / 21.4 ms at 2^24, profiles/r03_proj_*.json): the window a
+ *            bucket-sharded rank saves is paid back by walking all n scalars to keep an eighth of the
+ *            digits; POINTS holds 1/world of the key per device.  BUCKETS stays selectable (it is the
+ *            better cut where the per-device key does not matter and the windows differ more).      */
 enum { G16_SHARD_AUTO = 0, G16_SHARD_POINTS = 1, G16_SHARD_BUCKETS = 2 };
 
 /* The R1CS -> QAP reduction (the `QAP` type parameter of ark_groth16::Groth16<E, QAP>):
