@@ -50,6 +50,12 @@ MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
   cfg.D = (cfg.W + pn - 1) / pn;
   cfg.Pn = (cfg.W + cfg.D - 1) / cfg.D;
   cfg.B = 1u << (c - 1);
+  // G1 segment count: 3072 workgroups (two full rounds of the optimistic kernel's three waves per
+  // SIMD) only when a segment still holds ~100 entries; with shorter segments every bucket is cut
+  // into more partials than the wider grid is worth (same box: 2^22 proof 37.3 -> 37.2 ms with 3072,
+  // 2^20 proof 11.7 -> 12.3 ms)
+  if ((uint64_t)len * (uint64_t)cfg.W < (uint64_t)96 * MSM_ACC_BLOCKS * MSM_ACC_THREADS)
+    cfg.lanes = (uint32_t)MSM_ACC_BLOCKS_G2 * MSM_ACC_THREADS;
   if (const char* e = getenv("G16_ACC_GRID")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 65536) cfg.lanes = (uint32_t)v * MSM_ACC_THREADS;
