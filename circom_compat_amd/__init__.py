@@ -393,12 +393,15 @@ class Prover:
     def __init__(self, pk: Optional[ProvingKey], matrices: ConstraintMatrices, device=0, rank=0,
                  world=1, window_bits=0, planes=0, lib: Optional[B.Library] = None,
                  n_vars: Optional[int] = None, dist_wm=False, reduction: str = "circom",
-                 devices: Optional[Sequence[int]] = None, shard: str = "auto"):
+                 devices: Optional[Sequence[int]] = None, shard: str = "auto",
+                 sibling_of: Optional["Prover"] = None):
         """devices=[d0, d1, ...]: ONE ctx sharded over several GPUs inside the library
         (g16_ctx_create_multi); prove() / prove_dev() are then used exactly as on one device.
         shard (world > 1 / devices): "points" = point-range MSM shards, "buckets" = every rank holds
         all points of the witness queries and 1/world of their sorted bucket list (H stays cut by
-        point range), "auto" = buckets when the key fits."""
+        point range), "auto" = points.
+        sibling_of=prover: a second ctx on the same device that borrows `prover`'s point planes
+        (g16_ctx_create_sibling): two threads, two proofs in flight."""
         self.lib = lib or B.load()
         self.matrices = matrices
         self.pk = pk
@@ -429,7 +432,11 @@ class Prover:
         a, b = matrices.a.to_c(), matrices.b.to_c()
         ctx = C.c_void_p()
         self.devices = list(devices) if devices is not None else None
-        if self.devices is not None:
+        self._donor = sibling_of                          # keeps the lender alive
+        if sibling_of is not None:
+            st = self.lib.g16_ctx_create_sibling(sibling_of.ctx, C.byref(kd), C.byref(a), C.byref(b),
+                                                 matrices.num_constraints, C.byref(opt), C.byref(ctx))
+        elif self.devices is not None:
             opt.dist_wm = -1 if dist_wm is None else 0   # None: force a replicated witness map
             ids = (C.c_int * len(self.devices))(*self.devices)
             st = self.lib.g16_ctx_create_multi(C.byref(kd), C.byref(a), C.byref(b), matrices.num_constraints,

@@ -91,7 +91,7 @@ class R1csHeader(C.Structure):
 
 # every symbol include/*.h declares; tests assert the built library exports all of them
 ABI_SYMBOLS = [
-    "g16_ctx_create", "g16_ctx_destroy", "g16_last_error", "g16_witness_map", "g16_msm_g1",
+    "g16_ctx_create", "g16_ctx_create_sibling", "g16_ctx_destroy", "g16_last_error", "g16_witness_map", "g16_msm_g1",
     "g16_msm_g2", "g16_prove", "g16_prove_dev", "g16_prove_partial", "g16_prove_partial_dev",
     "g16_prove_finish", "g16_dist_exchange_bytes", "g16_prove_dist_phase1", "g16_prove_dist_phase2",
     "g16_prove_dist_phase3", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info",
@@ -132,6 +132,8 @@ class Library:
         sig = {
             "g16_ctx_create": (C.c_int, [C.POINTER(KeyDesc), C.POINTER(Csr), C.POINTER(Csr),
                                          C.c_uint32, C.POINTER(Options), C.POINTER(vp)]),
+            "g16_ctx_create_sibling": (C.c_int, [vp, C.POINTER(KeyDesc), C.POINTER(Csr), C.POINTER(Csr),
+                                                 C.c_uint32, C.POINTER(Options), C.POINTER(vp)]),
             "g16_ctx_destroy": (None, [vp]),
             "g16_last_error": (C.c_char_p, [vp]),
             "g16_witness_map": (C.c_int, [vp, vp, C.c_size_t, vp]),

@@ -416,8 +416,11 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return bad(G16_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
   if (o.device < 0 || o.device >= ndev) return bad(G16_ERR_INVALID, "bad device ordinal");
-  if (share_from && (share_from->device != o.device || !share_from->shard_buckets || !share_from->has_key))
-    return bad(G16_ERR_INVALID, "planes can only be shared with a bucket-sharded ctx on the same device");
+  // a lender's planes are whole-key planes: either a bucket-sharded rank's (multi-device ctx with
+  // repeated ordinals) or a plain single-device ctx's (g16_ctx_create_sibling: two proofs in flight)
+  if (share_from && (share_from->device != o.device || !share_from->has_key || share_from->multi ||
+                     !(share_from->shard_buckets || (share_from->world == 1 && o.world == 1 && !share_from->dist_wm && o.dist_wm <= 0))))
+    return bad(G16_ERR_INVALID, "planes can only be shared with a whole-key ctx on the same device");
 
   g16_ctx* c = new (std::nothrow) g16_ctx();
   if (!c) return bad(G16_ERR_INTERNAL, "host allocation failed");
@@ -496,7 +499,7 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     c->shard_buckets = (c->world > 1 || c->dist_wm) && c->has_key && o.shard == G16_SHARD_BUCKETS;
     if (c->shard_buckets && !share_from && !bucket_shard_fits(c->device, c->N, c->n, &o))
       throw std::runtime_error("G16_SHARD_BUCKETS: the full point planes of the witness queries do not fit this device");
-    c->share_from = c->shard_buckets ? share_from : nullptr;
+    c->share_from = (c->shard_buckets || c->world == 1) ? share_from : nullptr;
     // the H query is ALWAYS cut by point range: its scalars are born sharded (the distributed
     // witness map leaves rank g the n / world evaluations e = global_index(t)), so every rank
     // multiplies its own slice; only the witness-scalar queries (A, B1, B2, L: the witness is
@@ -583,9 +586,12 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       c->l_idx_min = first - c->w_lo;
       c->ptsL.init((const G1Affine*)key->l_query + (first - c->p), cnt, c->cfg_w, s);
     }
-    c->cfg_h = fit_config(lh ? lh : 1, o.window_bits, o.planes, 64, reserve);
+    const bool lend_h = lender && c->world == 1;  // a sibling of a single-device ctx: same H planes too
+    c->cfg_h = lend_h ? lender->cfg_h : fit_config(lh ? lh : 1, o.window_bits, o.planes, 64, reserve);
     c->sort_h.init(lh, c->cfg_h);
-    if (c->dist_wm) {
+    if (lend_h) {
+      borrow(c->ptsH, lender->ptsH);
+    } else if (c->dist_wm) {
       // this rank's h scalars are the evaluations e = global_index(t): gather the matching points
       std::vector<G1Affine> mine(lh);
       const G1Affine* hq = (const G1Affine*)key->h_query;
@@ -644,6 +650,23 @@ g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_c
                           uint32_t num_constraints, const g16_options* opt, g16_ctx** out) {
   std::string err;
   const g16_status st = ctx_create_impl(key, a, b, num_constraints, opt, nullptr, out, &err);
+  if (st != G16_OK) return fail(nullptr, st, err);
+  return G16_OK;
+}
+
+g16_status g16_ctx_create_sibling(g16_ctx* donor, const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
+                                  uint32_t num_constraints, const g16_options* opt, g16_ctx** out) {
+  if (!donor) return fail(nullptr, G16_ERR_INVALID, "null argument");
+  g16_options o{};
+  if (opt) o = *opt;
+  o.device = donor->device;
+  o.rank = 0;
+  o.world = 1;
+  o.dist_wm = 0;
+  if (key && (key->n_vars != donor->N || key->n_public != donor->p || key->domain_size != donor->n))
+    return fail(nullptr, G16_ERR_INVALID, "sibling: not the donor's key");
+  std::string err;
+  const g16_status st = ctx_create_impl(key, a, b, num_constraints, &o, donor, out, &err);
   if (st != G16_OK) return fail(nullptr, st, err);
   return G16_OK;
 }

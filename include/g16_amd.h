@@ -118,6 +118,14 @@ enum { G16_QUERY_A = 0, G16_QUERY_B1 = 1, G16_QUERY_L = 2, G16_QUERY_H = 3 };
 g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
                           uint32_t num_constraints, const g16_options* opt, g16_ctx** out);
 void g16_ctx_destroy(g16_ctx* ctx);
+/* A second prover over the SAME key on the donor's device that borrows the donor's point planes
+ * (no second copy of the 21 GiB at 2^22) and owns everything else (streams, sort state, workspaces):
+ * two host threads can then keep two proofs in flight, one per ctx -- the front of one (digit sort,
+ * witness map) runs under the bucket reductions and the finalisation of the other.  key / a / b as
+ * given to the donor (the descriptor's query pointers are not read again); the donor must outlive
+ * the sibling.  Throughput mode of a proving service; one proof's latency does not change.        */
+g16_status g16_ctx_create_sibling(g16_ctx* donor, const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
+                                  uint32_t num_constraints, const g16_options* opt, g16_ctx** out);
 const char* g16_last_error(const g16_ctx* ctx); /* ctx may be NULL: error of the last failed create */
 
 /* Single-process multi-device prover (`device_ids, n_dev`; section 8(e)).

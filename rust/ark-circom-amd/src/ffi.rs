@@ -146,6 +146,15 @@ pub struct g16_r1cs_header {
 extern "C" {
     // ---- include/g16_amd.h ---------------------------------------------------------------------
     pub fn g16_ctx_create(key: *const g16_key_desc, a: *const g16_csr, b: *const g16_csr, num_constraints: u32, opt: *const g16_options, out: *mut *mut g16_ctx) -> g16_status;
+    pub fn g16_ctx_create_sibling(
+        donor: *mut g16_ctx,
+        key: *const g16_key_desc,
+        a: *const g16_csr,
+        b: *const g16_csr,
+        num_constraints: u32,
+        opt: *const g16_options,
+        out: *mut *mut g16_ctx,
+    ) -> c_int;
     pub fn g16_ctx_destroy(ctx: *mut g16_ctx);
     pub fn g16_last_error(ctx: *const g16_ctx) -> *const c_char;
     pub fn g16_ctx_create_multi(key: *const g16_key_desc, a: *const g16_csr, b: *const g16_csr, num_constraints: u32, device_ids: *const c_int, n_dev: c_int, opt: *const g16_options, out: *mut *mut g16_ctx) -> g16_status;

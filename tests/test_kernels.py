@@ -675,3 +675,43 @@ def test_poseidon_shaped_generator_full_width_rows_vs_oracle(lib):
     pr = cc.Prover(pk, mats, lib=lib, devices=[0] * 4, shard="buckets")
     assert pr.prove(r, s, w).raw == want
     pr.close()
+
+
+def test_sibling_ctx_shares_planes_two_proofs_in_flight(lib, golden):
+    """g16_ctx_create_sibling: a second prover over the same key that borrows the donor's point planes.
+    Both give the oracle's bytes -- alternately and from two host threads at once (the throughput mode
+    of bench.py); closing the sibling leaves the donor working; a multi-device ctx cannot lend."""
+    import threading
+    import circom_compat_amd as cc
+    cons, w, n_vars, n_pub = H.squaring_chain(5)
+    rng = random.Random(55)
+    opk = o.trapdoor_setup(cons, n_vars, n_pub, *[rng.randrange(1, o.R_MOD) for _ in range(5)])
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, lib)
+    pk = H.pk_from_oracle(opk)
+    donor = cc.Prover(pk, mats, lib=lib)
+    sib = cc.Prover(pk, mats, lib=lib, sibling_of=donor)
+    rs = [(rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)) for _ in range(2)]
+    want = [o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2,
+                                                                        len(cons), w)) for r, s in rs]
+    assert donor.prove(*rs[0], w).raw == want[0] and sib.prove(*rs[1], w).raw == want[1]
+    assert sib.prove(*rs[0], w).raw == want[0] and donor.prove(*rs[1], w).raw == want[1]
+    if not lib.path.endswith("libg16_emu.so"):            # the emulator is single-threaded by construction
+        got = [None, None]
+
+        def run(i, p):
+            for _ in range(3):
+                got[i] = p.prove(*rs[i], w).raw
+        ths = [threading.Thread(target=run, args=(i, p)) for i, p in enumerate((donor, sib))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert got == want
+    sib.close()
+    assert donor.prove(*rs[0], w).raw == want[0]
+    multi = cc.Prover(pk, mats, lib=lib, devices=[0, 0])
+    with pytest.raises(cc.G16Error):
+        cc.Prover(pk, mats, lib=lib, sibling_of=multi)
+    multi.close()
+    donor.close()
