@@ -26,6 +26,11 @@ inline bool acc_fast() {
   static const bool v = [] { const char* e = getenv("G16_ACC_FAST"); return !e || atoi(e) != 0; }();
   return v;
 }
+// G16_ACC_FAST_G2=1: the optimistic kernel for the G2 launch as well (measured: see DESIGN.md section 5)
+inline bool acc_fast_g2() {
+  static const bool v = [] { const char* e = getenv("G16_ACC_FAST_G2"); return e && atoi(e) != 0; }();
+  return v;
+}
 constexpr int COMB_THREADS = 64;
 constexpr int SUM_THREADS = 128;
 
@@ -193,8 +198,13 @@ __device__ __forceinline__ void acc_way_commit(AccWay<F>& w, bool step,
 // iteration or two of each other and the later one finds the line in the cache.
 // FAST (G1): optimistic kernel, see acc_way_commit; !FAST with a list: the exact kernel launched
 // behind it, which returns at once unless the list overflowed (fix->overflow, set by k_acc_fixup).
+#ifdef G16_ACC_WAVES2  // experiment: cap the kernel at 256 VGPRs (two waves per SIMD for the G2 optimistic variant)
+#define G16_ACC_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define G16_ACC_ATTR
+#endif
 template <class F, int PS, bool PAIR, bool FAST>
-__global__ void __launch_bounds__(ACC_THREADS)
+__global__ void __launch_bounds__(ACC_THREADS) G16_ACC_ATTR
     k_bucket_accumulate(const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min,
                         const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset,
                         uint32_t nb, uint32_t lanes, MsmAcc<F>* __restrict__ partial,
@@ -559,8 +569,8 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
   MsmAcc<F>* out = work.partial.p + (size_t)slot * work.slots;
   const uint32_t* en = (const uint32_t*)s.entries.p;
   const uint32_t* of = (const uint32_t*)s.offset.p;
-  if constexpr (sizeof(F) == sizeof(Fq)) {
-    if (acc_fast()) {
+  {
+    if (sizeof(F) == sizeof(Fq) ? acc_fast() : acc_fast_g2()) {
       // optimistic kernel, deferred exact additions, exact kernel (returns at once unless the list overflowed)
       MsmFixList* fix = work.fix.p;
       if (P.stride == 2) {
