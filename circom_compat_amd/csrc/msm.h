@@ -27,9 +27,14 @@
 namespace g16 {
 
 constexpr int MSM_ACC_THREADS = 128;    // workgroup of the accumulation kernel
+#ifdef G16_EMU  // the CPU SIMT emulator steps through every thread of a launch: tests use small grids
+constexpr int MSM_ACC_BLOCKS = 48;
+constexpr int MSM_ACC_BLOCKS_G2 = 32;
+#else
 constexpr int MSM_ACC_BLOCKS = 3072;    // G1: segments = 3072 x 128 -- two rounds of the optimistic kernel's 3 waves per SIMD on 256 CUs (G16_ACC_GRID overrides)
 constexpr int MSM_ACC_BLOCKS_G2 = 2048; // G2: 2048 x 128 (one wave per SIMD, four rounds; G16_ACC_GRID_G2 overrides).  Same box, 2^22,
                                         // ms per launch at 2048 / 3072 workgroups: A|B1 pair 9.69 / 9.38, L or H 4.73 / 4.49, B2 12.1 / 12.8
+#endif
 constexpr int MSM_MIN_SEG = 8;          // shortest per-lane segment
 constexpr int MSM_SMALL_MULTI = 32;     // buckets with <= this many partials are summed inside the reduce
 constexpr int MSM_RED_CHUNK = 16;   // max buckets per thread in the weighted bucket reduction

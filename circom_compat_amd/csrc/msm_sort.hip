@@ -499,7 +499,11 @@ static uint32_t sort_grid_cap() {
   static const uint32_t cap = [] {
     const char* e = getenv("G16_SORT_GRID");
     const int v = e ? atoi(e) : 0;
+#ifdef G16_EMU
+    return v > 0 && v <= 8192 ? (uint32_t)v : 32u;  // emulator: every thread of a launch is stepped through
+#else
     return v > 0 && v <= 8192 ? (uint32_t)v : 2048u;
+#endif
   }();
   return cap;
 }

@@ -2,10 +2,13 @@
 // parent ctx whose children are one sharded rank per device.
 //
 // What is sharded (north_star: "MSM shards by point-range across the 8 GPUs ... partial sums over
-// xGMI"): every query array is cut by contiguous point range at create time, and -- when the device
-// count is a power of two -- the witness map is distributed as well (wm_dist.h: four-step NTTs whose
-// two transposes are all-to-all exchanges).  Nothing of a proof touches the host between the
-// witness upload and the 256-byte download:
+// xGMI"): the MSMs -- every query array cut by contiguous point range at create time (G16_SHARD_POINTS,
+// what AUTO selects), or the four witness-scalar queries cut by BUCKET range (G16_SHARD_BUCKETS: every
+// device holds all their points and the single-GPU window and keeps 1/G of the sorted bucket list;
+// ranks that repeat a device ordinal borrow the first one's planes) -- and, when the device count is
+// a power of two, the witness map as well (wm_dist.h: four-step NTTs whose two transposes are
+// all-to-all exchanges).  Nothing of a proof touches the host between the witness upload and the
+// 256-byte download:
 //   * exchanges are PUSHED with hipMemcpyPeerAsync, one copy stream per destination so that all
 //     seven xGMI links of a device carry one chunk each at the same time (xGMI is point-to-point:
 //     an all-to-all IS seven independent peer copies per device; there is no ring to build);

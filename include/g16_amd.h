@@ -129,8 +129,9 @@ g16_status g16_ctx_create_sibling(g16_ctx* donor, const g16_key_desc* key, const
 const char* g16_last_error(const g16_ctx* ctx); /* ctx may be NULL: error of the last failed create */
 
 /* Single-process multi-device prover (`device_ids, n_dev`; section 8(e)).
- * One sharded rank per listed device INSIDE the library: every query is cut by contiguous point
- * range over the devices and (n_dev a power of two) the witness map becomes four-step NTTs whose two
+ * One sharded rank per listed device INSIDE the library: the MSMs are cut over the devices as
+ * opt->shard says (point ranges by default, G16_SHARD_* below) and (n_dev a power of two) the witness
+ * map becomes four-step NTTs whose two
  * all-to-all transposes are hipMemcpyPeerAsync pushes over xGMI, one copy stream per peer link;
  * the 1 KiB partial records are peer-copied to device_ids[0] and summed there.  The returned ctx is
  * used like a single-device one: g16_prove / g16_prove_dev (w_dev on device_ids[0]) shard
@@ -138,7 +139,9 @@ const char* g16_last_error(const g16_ctx* ctx); /* ctx may be NULL: error of the
  * download.  Replaces the same reference call as g16_ctx_create + g16_prove
  * (benches/groth16.rs:52-60); a Rust caller needs no launcher and no collective library.
  * opt->device / rank / world / dist_wm are ignored (dist_wm < 0 forces a replicated witness map).
- * device_ids may repeat an ordinal (several ranks time-sharing one GPU: functional tests).         */
+ * device_ids may repeat an ordinal (several ranks time-sharing one GPU: functional tests).
+ * Direct peer access between the devices is requested and REPORTED (g16_ctx_info out[14]; one line on
+ * stderr when the runtime will stage copies; G16_REQUIRE_PEER_ACCESS=1 makes that an error).        */
 g16_status g16_ctx_create_multi(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
                                 uint32_t num_constraints, const int* device_ids, int n_dev,
                                 const g16_options* opt, g16_ctx** out);

@@ -13,6 +13,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -28,17 +29,20 @@ def traffic(m):
 
 def main(root, log2, out):
     # single-query launches (L, H; every G1 launch when G16_NO_PAIR_AB=1) / the A|B1 pair launch
-    acc, pair, g2 = defaultdict(list), defaultdict(list), defaultdict(list)
+    acc, pair, g2_d = defaultdict(list), defaultdict(list), defaultdict(list)
     for path in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
         with open(path) as f:
             for row in csv.DictReader(f):
                 name = row["Kernel_Name"]
-                if "k_bucket_accumulate<g16::Fq2" in name:
-                    g2[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                mt = re.search(r"k_bucket_accumulate<(.*?), (\d), (true|false)(?:, (true|false))?>", name)
+                if not mt:
                     continue
-                if "k_bucket_accumulate<g16::Fp<" not in name:
+                g2, pair_l, fast = "Fq2" in mt.group(1), mt.group(3) == "true", mt.group(4)
+                # round 3: G1 launches are the optimistic variant (FAST = true); the exact variant behind
+                # it returns at once (its counters are noise), G2 keeps the exact kernel
+                if fast is not None and (fast == "true") == g2:
                     continue
-                (pair if "2, true>" in name else acc)[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                (g2_d if g2 else pair if pair_l else acc)[row["Counter_Name"]].append(float(row["Counter_Value"]))
     m = {k: sum(v) / len(v) for k, v in acc.items()}
     read_bytes, write_bytes = traffic(m)
     rec = {"kernel": "k_bucket_accumulate<Fq, 1, false>", "log2_domain": int(log2), "launches_averaged": len(acc.get("TCC_EA0_RDREQ", [])),
@@ -52,8 +56,8 @@ def main(root, log2, out):
         rec.update({"pair_kernel": "k_bucket_accumulate<Fq, 2, true> (A and B1 over interleaved records, one launch)",
                     "pair_read_bytes_per_launch": pr, "pair_write_bytes_per_launch": pw,
                     "pair_traffic_bytes_per_launch": pr + pw, "pair_counters": mp})
-    if g2:
-        mg = {k: sum(v) / len(v) for k, v in g2.items()}
+    if g2_d:
+        mg = {k: sum(v) / len(v) for k, v in g2_d.items()}
         gr, gw = traffic(mg)
         rec.update({"g2_kernel": "k_bucket_accumulate<Fq2, 1, false> (B2 query)",
                     "g2_read_bytes_per_launch": gr, "g2_write_bytes_per_launch": gw,
