@@ -24,7 +24,7 @@ mod reduction;
 mod verify;
 
 pub use ark_circom::{circom, read_zkey, CircomBuilder, CircomCircuit, CircomConfig, CircomReduction, Wasm, WitnessCalculator};
-pub use prover::{GpuError, GpuProver, Reduction};
+pub use prover::{GpuError, GpuProver, Reduction, Shard};
 pub use reduction::GpuCircomReduction;
 pub use verify::verify_batch;
 

@@ -59,6 +59,14 @@ fn check(ctx: *const ffi::g16_ctx, st: c_int) -> Result<(), GpuError> {
     }
 }
 
+/// How `with_devices_sharded` cuts the MSMs over the devices (`G16_SHARD_*`, include/g16_amd.h).
+#[derive(Clone, Copy, PartialEq, Eq, Debug)]
+pub enum Shard {
+    Auto,
+    Points,
+    Buckets,
+}
+
 impl GpuProver {
     /// The inputs `read_zkey` returns (src/zkey.rs:53-60), on one GPU.
     pub fn new(pk: &ProvingKey<Bn254>, matrices: &ConstraintMatrices<Fr>) -> Result<Self, GpuError> {
@@ -73,6 +81,20 @@ impl GpuProver {
         matrices: &ConstraintMatrices<Fr>,
         devices: &[i32],
         reduction: Reduction,
+    ) -> Result<Self, GpuError> {
+        Self::with_devices_sharded(pk, matrices, devices, reduction, Shard::Auto)
+    }
+
+    /// The same with the cut of the MSMs named (`g16_options.shard`): `Shard::Points` = every device
+    /// holds 1/n of the key, `Shard::Buckets` = every device holds all points of the witness queries
+    /// and the single-GPU window and works on 1/n of the sorted bucket list (same time per rank,
+    /// DESIGN.md section 7); `Shard::Auto` = points.
+    pub fn with_devices_sharded(
+        pk: &ProvingKey<Bn254>,
+        matrices: &ConstraintMatrices<Fr>,
+        devices: &[i32],
+        reduction: Reduction,
+        shard: Shard,
     ) -> Result<Self, GpuError> {
         let n_vars = pk.a_query.len();
         let n_public = pk.vk.gamma_abc_g1.len() - 1;
@@ -109,6 +131,11 @@ impl GpuProver {
         let (va, vb) = (ca.view(), cb.view());
         let opt = ffi::g16_options {
             reduction: if reduction == Reduction::Libsnark { ffi::G16_REDUCTION_LIBSNARK } else { ffi::G16_REDUCTION_CIRCOM },
+            shard: match shard {
+                Shard::Auto => ffi::G16_SHARD_AUTO,
+                Shard::Points => ffi::G16_SHARD_POINTS,
+                Shard::Buckets => ffi::G16_SHARD_BUCKETS,
+            },
             ..Default::default()
         };
         let mut ctx: *mut ffi::g16_ctx = std::ptr::null_mut();
