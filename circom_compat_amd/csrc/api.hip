@@ -72,12 +72,21 @@ void collect_times(g16_ctx* c) {
 }
 
 // A and B1 accumulations into work1 slots 0 and 1: one launch over the interleaved pair, or two
-void accumulate_ab(g16_ctx* c, hipStream_t s, StageTimer* tm) {
+void accumulate_ab(g16_ctx* c, hipStream_t s, StageTimer* tm, bool fixup = true) {
   if (c->ptsA.stride == 2) {
-    msm_accumulate_pair<Fq>(c->sort_w, c->ptsA, c->ptsB1, c->work1, 0, s, tm);
+    msm_accumulate_pair<Fq>(c->sort_w, c->ptsA, c->ptsB1, c->work1, 0, s, tm, fixup);
   } else {
-    msm_accumulate<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, s, tm);
-    msm_accumulate<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, s, tm);
+    msm_accumulate<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, s, tm, fixup);
+    msm_accumulate<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, s, tm, fixup);
+  }
+}
+// the deferred exact additions of accumulate_ab(fixup = false), on the stream that reduces A and B1
+void fixup_ab(g16_ctx* c, hipStream_t q) {
+  if (c->ptsA.stride == 2) {
+    msm_fixup_pair<Fq>(c->sort_w, c->ptsA, c->ptsB1, c->work1, 0, q);
+  } else {
+    msm_fixup<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, q);
+    msm_fixup<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, q);
   }
 }
 
@@ -120,20 +129,28 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     // sets: three reductions in a row outlast the accumulations, the batched path below wins),
     // 2^18 5.25 / 5.06, 2^19 8.03 / 7.46, 2^20 13.46 / 12.49, 2^21 23.1 / 23.1 (larger sets: the
     // reductions take issue slots from a saturated accumulation).
+    // The single-block fix-up of the optimistic G1 kernel goes with the reduction: on the main
+    // stream it would sit between two accumulations and wait for a wave slot of a chip that the
+    // red / aux streams keep busy (0.4 ms in a rank's timeline).  Same box, fix-up inline / on the
+    // reducing stream: 2^20 proof 11.6-11.8 / 11.4 ms, one point-sharded rank of 8 at 2^22 7.9-8.0 / 7.8 ms
+    // (scripts/gpu_r3_run13.sh; G16_FIXUP_INLINE=1 is the A/B knob).
     hipStream_t q = c->red;
-    accumulate_ab(c, s, tm);
+    static const bool fix_inline = [] { const char* e = getenv("G16_FIXUP_INLINE"); return e && atoi(e) != 0; }();  // A/B knob
+    accumulate_ab(c, s, tm, /*fixup=*/fix_inline);
     G16_HIP(hipEventRecord(c->ev_acc[0], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[0], 0));
-    msm_reduce<Fq>(c->sort_w, c->work1, 0, 2, &S->A, q, tm);
+    if (!fix_inline) fixup_ab(c, q);
+    msm_reduce<Fq>(c->sort_w, c->work1, 0, 2, &S->A, q, tm, /*hidden=*/true);
     after_ab(q);
     msm_accumulate<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, 0, s, tm);
     G16_HIP(hipEventRecord(c->ev_acc[1], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[1], 0));
-    msm_reduce<Fq2>(c->sort_w, c->work2, 0, 1, &S->B2, q, tm);
-    msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm);
+    msm_reduce<Fq2>(c->sort_w, c->work2, 0, 1, &S->B2, q, tm, /*hidden=*/true);
+    msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm, /*fixup=*/fix_inline);
     G16_HIP(hipEventRecord(c->ev_acc[2], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[2], 0));
-    msm_reduce<Fq>(c->sort_w, c->work1, 2, 1, &S->L, q, tm);
+    if (!fix_inline) msm_fixup<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, q);
+    msm_reduce<Fq>(c->sort_w, c->work1, 2, 1, &S->L, q, tm, /*hidden=*/true);
     after_b2();
     G16_HIP(hipEventRecord(c->ev_b2, q));
     G16_HIP(hipStreamWaitEvent(c->side, c->ev_b2, 0));  // the side stream joins: one event to wait on

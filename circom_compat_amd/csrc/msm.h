@@ -77,11 +77,23 @@ inline int msm_part_shift(uint32_t nb) {
 // `world` > 1 (bucket-range sharding, MsmSort::set_shard): this rank reduces ~1/world of the bucket
 // set, so the chunk shrinks with it (the threads outside the rank's range exit at once); a chunk
 // never exceeds a level-1 sort partition, whose boundaries the rank ranges are cut at.
-inline uint32_t msm_red_chunk(const MsmConfig& cfg, uint32_t nbatch = 1, uint32_t world = 1) {
-  static const uint32_t lanes_target = [] {
+// `hidden`: the reduction runs on the `red` stream underneath the next accumulation.  There its
+// additions cost accumulation issue slots (65536 threads of one bucket do 25 additions per bucket,
+// 8192 threads of 8 buckets 5.3), but its latency still matters: the reductions of a proof queue up
+// on that one stream and the variable-base products wait for the first of them.  Measured on one box
+// (scripts/gpu_r3_run13.sh; 2^20 proof / one rank of 8 at 2^22, ms): 65536 threads 11.4-11.8 / 7.8-8.0,
+// 16384 threads 11.5-11.9 / 7.7-8.1, 8192 threads 12.4-12.5 / 8.9-9.1 -- the narrow reductions finish
+// after the last accumulation.  So hidden reductions keep the exposed width; G16_RED_LANES_HIDDEN overrides.
+inline uint32_t msm_red_chunk(const MsmConfig& cfg, uint32_t nbatch = 1, uint32_t world = 1, bool hidden = false) {
+  static const uint32_t lanes_exposed = [] {
     const char* e = getenv("G16_RED_LANES");  // tuning knob: threads the reduction aims for
     return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 65536u;
   }();
+  static const uint32_t lanes_hidden = [] {
+    const char* e = getenv("G16_RED_LANES_HIDDEN");
+    return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 65536u;
+  }();
+  const uint32_t lanes_target = hidden ? lanes_hidden : lanes_exposed;
   uint32_t ch = (uint32_t)(((uint64_t)nbatch * cfg.D * cfg.B) / ((uint64_t)lanes_target * (world ? world : 1)));
   if (ch < 1) ch = 1;
   static const uint32_t ch_max = [] {
@@ -188,7 +200,7 @@ struct MsmWork {
   DevBuf<MsmAcc<F>> contrib;  // [batch][ncontrib]: one per reduction chunk
   DevBuf<MsmAcc<F>> bsum;     // [batch][256 * sets]: intermediate tree level
   DevBuf<MsmAcc<F>> wsum;     // [batch][sets]: one per bucket set
-  DevBuf<MsmFixList> fix;     // deferred exact additions of the G1 accumulation launch in flight
+  DevBuf<MsmFixList> fix;     // [batch]: deferred exact additions of the accumulation into each slot
   // sized for the larger of several sorts that will share this workspace
   void init(uint32_t n_slots, uint32_t n_contrib, int max_sets, int batch = 1);
 };
@@ -200,18 +212,29 @@ void msm_run(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min, MsmWor
              MsmAcc<F>* out_dev, hipStream_t stream, StageTimer* tm = nullptr);
 // The two halves of msm_run, for MSMs that share a sort (A, B1, L over the witness scalars): their
 // accumulations go into different workspace slots and ONE batched reduction finishes all of them.
+// fixup = false (G1 only): just the optimistic kernel; the caller runs msm_fixup on the stream that
+// reduces this slot, so that the single-block fix-up never sits between two accumulations
 template <class F>
 void msm_accumulate(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min, MsmWork<F>& work,
-                    int slot, hipStream_t stream, StageTimer* tm = nullptr);
+                    int slot, hipStream_t stream, StageTimer* tm = nullptr, bool fixup = true);
+// the deferred exact additions of the accumulation(s) into `slot` (an interleaved pair: both halves,
+// slots `slot` and `slot + 1`): k_acc_fixup + the exact kernel that redoes an overflowed launch
+template <class F>
+void msm_fixup(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min, MsmWork<F>& work, int slot,
+               hipStream_t stream);
 // a, b: the two halves of an interleaved pair (MsmPoints::init_pair).  ONE launch: the two waves of
 // a workgroup walk the same 64 segments, wave 0 adding a's points into `slot`, wave 1 b's points into
 // `slot + 1` -- the second wave finds the 128-byte line its neighbour just pulled in the cache.
 template <class F>
 void msm_accumulate_pair(const MsmSort& s, const MsmPoints<F>& a, const MsmPoints<F>& b,
-                         MsmWork<F>& work, int slot, hipStream_t stream, StageTimer* tm = nullptr);
+                         MsmWork<F>& work, int slot, hipStream_t stream, StageTimer* tm = nullptr,
+                         bool fixup = true);
+template <class F>
+void msm_fixup_pair(const MsmSort& s, const MsmPoints<F>& a, const MsmPoints<F>& b, MsmWork<F>& work,
+                    int slot, hipStream_t stream);
 template <class F>
 void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, MsmAcc<F>* out_dev,
-                hipStream_t stream, StageTimer* tm = nullptr);
+                hipStream_t stream, StageTimer* tm = nullptr, bool hidden = false);
 
 
 

@@ -541,13 +541,13 @@ void MsmWork<F>::init(uint32_t n_slots, uint32_t n_contrib, int max_sets, int ba
   contrib.alloc((size_t)batch * ncontrib);
   bsum.alloc((size_t)batch * 256 * sets);
   wsum.alloc((size_t)batch * sets);
-  fix.alloc(1);
-  G16_HIP(hipMemset(fix.p, 0, sizeof(MsmFixList)));
+  fix.alloc((size_t)batch);
+  G16_HIP(hipMemset(fix.p, 0, (size_t)batch * sizeof(MsmFixList)));
 }
 
 template <class F>
 void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<F>& work,
-                    int slot, hipStream_t stream, StageTimer* tm) {
+                    int slot, hipStream_t stream, StageTimer* tm, bool fixup) {
   const MsmConfig& cfg = s.cfg;
   const uint32_t nb = cfg.nb();
   const int acc_stage = sizeof(F) == sizeof(Fq) ? ST_MSM_ACC_G1 : ST_MSM_ACC_G2;
@@ -569,26 +569,18 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
   MsmAcc<F>* out = work.partial.p + (size_t)slot * work.slots;
   const uint32_t* en = (const uint32_t*)s.entries.p;
   const uint32_t* of = (const uint32_t*)s.offset.p;
-  {
-    if (sizeof(F) == sizeof(Fq) ? acc_fast() : acc_fast_g2()) {
-      // optimistic kernel, deferred exact additions, exact kernel (returns at once unless the list overflowed)
-      MsmFixList* fix = work.fix.p;
-      if (P.stride == 2) {
-        G16_LAUNCH((k_bucket_accumulate<F, 2, false, true>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
-                   P.count, idx_min, en, of, nb, lanes, out, (size_t)0, fix);
-        G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, P.data() + P.off, P.count, idx_min, fix, out, (size_t)0);
-        G16_LAUNCH((k_bucket_accumulate<F, 2, false, false>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
-                   P.count, idx_min, en, of, nb, lanes, out, (size_t)0, fix);
-      } else {
-        G16_LAUNCH((k_bucket_accumulate<F, 1, false, true>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
-                   idx_min, en, of, nb, lanes, out, (size_t)0, fix);
-        G16_LAUNCH((k_acc_fixup<F, 1>), 1, 256, 0, stream, P.data(), P.count, idx_min, fix, out, (size_t)0);
-        G16_LAUNCH((k_bucket_accumulate<F, 1, false, false>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
-                   idx_min, en, of, nb, lanes, out, (size_t)0, fix);
-      }
-      if (tm) tm->end(id, stream);
-      return;
-    }
+  if (sizeof(F) == sizeof(Fq) ? acc_fast() : acc_fast_g2()) {
+    // optimistic kernel; the deferred exact additions follow (msm_fixup), here or on the reducing stream
+    MsmFixList* fix = work.fix.p + slot;
+    if (P.stride == 2)
+      G16_LAUNCH((k_bucket_accumulate<F, 2, false, true>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
+                 P.count, idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+    else
+      G16_LAUNCH((k_bucket_accumulate<F, 1, false, true>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
+                 idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+    if (tm) tm->end(id, stream);
+    if (fixup) msm_fixup<F>(s, P, idx_min, work, slot, stream);
+    return;
   }
   if (P.stride == 2)
     G16_LAUNCH((k_bucket_accumulate<F, 2, false, false>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
@@ -600,8 +592,32 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
 }
 
 template <class F>
+void msm_fixup(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<F>& work, int slot,
+               hipStream_t stream) {
+  if (!(sizeof(F) == sizeof(Fq) ? acc_fast() : acc_fast_g2())) return;
+  const MsmConfig& cfg = s.cfg;
+  const uint32_t nb = cfg.nb();
+  const uint32_t lanes = s.lanes_of(sizeof(F) != sizeof(Fq));
+  const uint32_t grid = lanes / ACC_THREADS;
+  MsmAcc<F>* out = work.partial.p + (size_t)slot * work.slots;
+  const uint32_t* en = (const uint32_t*)s.entries.p;
+  const uint32_t* of = (const uint32_t*)s.offset.p;
+  MsmFixList* fix = work.fix.p + slot;
+  // exact additions of the listed points, then the exact kernel (returns at once unless the list overflowed)
+  if (P.stride == 2) {
+    G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, P.data() + P.off, P.count, idx_min, fix, out, (size_t)0);
+    G16_LAUNCH((k_bucket_accumulate<F, 2, false, false>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
+               P.count, idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+  } else {
+    G16_LAUNCH((k_acc_fixup<F, 1>), 1, 256, 0, stream, P.data(), P.count, idx_min, fix, out, (size_t)0);
+    G16_LAUNCH((k_bucket_accumulate<F, 1, false, false>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
+               idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+  }
+}
+
+template <class F>
 void msm_accumulate_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoints<F>& B,
-                         MsmWork<F>& work, int slot, hipStream_t stream, StageTimer* tm) {
+                         MsmWork<F>& work, int slot, hipStream_t stream, StageTimer* tm, bool fixup) {
   const MsmConfig& cfg = s.cfg;
   const uint32_t nb = cfg.nb();
   const int acc_stage = ST_MSM_ACC_G1_PAIR;
@@ -617,13 +633,10 @@ void msm_accumulate_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoint
   MsmAcc<F>* out = work.partial.p + (size_t)slot * work.slots;
   if constexpr (sizeof(F) == sizeof(Fq)) {
     if (acc_fast()) {
-      MsmFixList* fix = work.fix.p;
       G16_LAUNCH((k_bucket_accumulate<F, 2, true, true>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
-                 en, of, nb, cfg.lanes, out, (size_t)work.slots, fix);
-      G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, A.data(), A.count, 0u, fix, out, (size_t)work.slots);
-      G16_LAUNCH((k_bucket_accumulate<F, 2, true, false>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
-                 en, of, nb, cfg.lanes, out, (size_t)work.slots, fix);
+                 en, of, nb, cfg.lanes, out, (size_t)work.slots, work.fix.p + slot);
       if (tm) tm->end(id, stream);
+      if (fixup) msm_fixup_pair<F>(s, A, B, work, slot, stream);
       return;
     }
   }
@@ -632,12 +645,30 @@ void msm_accumulate_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoint
   if (tm) tm->end(id, stream);
 }
 
+template <class F>
+void msm_fixup_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoints<F>& B, MsmWork<F>& work,
+                    int slot, hipStream_t stream) {
+  (void)B;
+  if constexpr (sizeof(F) == sizeof(Fq)) {
+    if (!acc_fast()) return;
+    const MsmConfig& cfg = s.cfg;
+    const uint32_t nb = cfg.nb();
+    const uint32_t grid = cfg.lanes / (ACC_THREADS / 2);
+    MsmAcc<F>* out = work.partial.p + (size_t)slot * work.slots;
+    MsmFixList* fix = work.fix.p + slot;
+    G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, A.data(), A.count, 0u, fix, out, (size_t)work.slots);
+    G16_LAUNCH((k_bucket_accumulate<F, 2, true, false>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
+               (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb, cfg.lanes, out,
+               (size_t)work.slots, fix);
+  }
+}
+
 // Bucket reduction of `nbatch` MSMs (workspace slots first_slot ...) that were accumulated over
 // the SAME sort: the reduction is a chain of dependent EC additions (~0.3-0.5 ms of latency
 // whatever the size), so MSMs sharing a sort pay it once.  out_dev: nbatch consecutive sums.
 template <class F>
 void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, MsmAcc<F>* out_dev,
-                hipStream_t stream, StageTimer* tm) {
+                hipStream_t stream, StageTimer* tm, bool hidden) {
   const MsmConfig& cfg = s.cfg;
   const uint32_t nb = cfg.nb();
   if (first_slot < 0 || nbatch < 1 || first_slot + nbatch > work.batch)
@@ -652,7 +683,7 @@ void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, 
   // buckets per thread: the running sums are a dependent chain of EC additions (~10 us each on
   // one lane): see msm_red_chunk for the thread count this aims at
   const uint32_t* rng = s.range_dev();  // bucket-range sharding: this rank's run of the bucket set
-  const uint32_t red_chunk = msm_red_chunk(cfg, (uint32_t)nbatch, (uint32_t)s.world);
+  const uint32_t red_chunk = msm_red_chunk(cfg, (uint32_t)nbatch, (uint32_t)s.world, hidden);
   const uint32_t cps = ceil_div(cfg.B, red_chunk);
   const uint32_t nchunks = cps * (uint32_t)cfg.D;
   if (nchunks > work.ncontrib) throw std::runtime_error("msm_reduce: contribution buffer too small");
