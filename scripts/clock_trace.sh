@@ -8,7 +8,7 @@ sample() {  # $1 = label, $2 = pid to watch
     sleep 0.3
   done
 }
-python bench.py --steps 300 --warmup 2 --cpu-log2 0 > gpurun_out/clock_trace_bench.json 2>/dev/null &
+G16_BENCH_NO_PIPELINE=1 python bench.py --steps 300 --warmup 2 --cpu-log2 0 > gpurun_out/clock_trace_bench.json 2>/dev/null &
 sample prove $!
 python - <<'PY' &
 import ctypes as C, sys
