@@ -20,6 +20,7 @@ namespace g16 {
 namespace {
 
 constexpr int ACC_THREADS = MSM_ACC_THREADS;
+constexpr uint32_t MSM_EXACT_BLOCKS = 256;  // workgroups of the exact kernel behind an optimistic launch
 
 // G16_ACC_FAST=0: the exact in-kernel redo only (A/B partner of the optimistic G1 kernel)
 inline bool acc_fast() {
@@ -603,14 +604,21 @@ void msm_fixup(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWor
   const uint32_t* en = (const uint32_t*)s.entries.p;
   const uint32_t* of = (const uint32_t*)s.offset.p;
   MsmFixList* fix = work.fix.p + slot;
-  // exact additions of the listed points, then the exact kernel (returns at once unless the list overflowed)
+  // exact additions of the listed points, then the exact kernel (returns at once unless the list
+  // overflowed).  The exact kernel is launched as a SMALL persistent grid (its threads loop over the
+  // segments): all of its workgroups have to be placed just to read one word, and with 219 VGPRs
+  // they only fit where an accumulation wave has retired -- 6144 workgroups of the pair launch took
+  // 0.78 ms to drain through a running G2 accumulation on a sharded rank's `red` stream
+  // (profiles/r03_rank8_timeline_k22_points_fixup_inline.txt's successor); a degenerate key that
+  // overflows the list pays for the narrow grid, nobody else.
+  const uint32_t grid_x = grid < MSM_EXACT_BLOCKS ? grid : MSM_EXACT_BLOCKS;
   if (P.stride == 2) {
     G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, P.data() + P.off, P.count, idx_min, fix, out, (size_t)0);
-    G16_LAUNCH((k_bucket_accumulate<F, 2, false, false>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
+    G16_LAUNCH((k_bucket_accumulate<F, 2, false, false>), grid_x, ACC_THREADS, 0, stream, P.data() + P.off,
                P.count, idx_min, en, of, nb, lanes, out, (size_t)0, fix);
   } else {
     G16_LAUNCH((k_acc_fixup<F, 1>), 1, 256, 0, stream, P.data(), P.count, idx_min, fix, out, (size_t)0);
-    G16_LAUNCH((k_bucket_accumulate<F, 1, false, false>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
+    G16_LAUNCH((k_bucket_accumulate<F, 1, false, false>), grid_x, ACC_THREADS, 0, stream, P.data(), P.count,
                idx_min, en, of, nb, lanes, out, (size_t)0, fix);
   }
 }
@@ -656,8 +664,9 @@ void msm_fixup_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoints<F>&
     const uint32_t grid = cfg.lanes / (ACC_THREADS / 2);
     MsmAcc<F>* out = work.partial.p + (size_t)slot * work.slots;
     MsmFixList* fix = work.fix.p + slot;
+    const uint32_t grid_x = grid < MSM_EXACT_BLOCKS ? grid : MSM_EXACT_BLOCKS;  // see msm_fixup
     G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, A.data(), A.count, 0u, fix, out, (size_t)work.slots);
-    G16_LAUNCH((k_bucket_accumulate<F, 2, true, false>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
+    G16_LAUNCH((k_bucket_accumulate<F, 2, true, false>), grid_x, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
                (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb, cfg.lanes, out,
                (size_t)work.slots, fix);
   }
