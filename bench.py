@@ -14,9 +14,10 @@ section 8(d) with m = 2^22 - 2 constraints, a real trapdoor key minted on the GP
 The SURVEY 8(d) step (host witness -> H2D -> ... -> 256 B D2H, witness in the ctx's page-locked
 staging buffer) is timed right after it and reported as `value_pcie_inclusive`.
 
-N > 1 (strong scaling of ONE proof): witness-scalar MSMs sharded by bucket range (--shard buckets /
-auto: every GPU holds all A/B1/B2/L points and the single-GPU window, keeps 1/N of the sorted bucket
-list; the only MSM traffic is a 1 KiB record per rank) or by point range (--shard points; H always),
+N > 1 (strong scaling of ONE proof): MSMs sharded by point range (--shard points / auto: every GPU
+holds 1/N of the key) or, for the witness-scalar queries, by bucket range (--shard buckets: every GPU
+holds all A/B1/B2/L points and the single-GPU window and keeps 1/N of the sorted bucket list; the
+only MSM traffic either way is a 1 KiB record per rank; same rank time),
 witness map distributed (four-step NTTs, two all-to-all exchanges), records gathered and summed.
   mode "in-library"  (default when this process can see N devices): rank 0 drives all N GPUs through
                      ONE g16_ctx_create_multi ctx -- exchanges are peer copies over xGMI inside the
@@ -377,7 +378,7 @@ def main():
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--planes", type=int, default=0)
     ap.add_argument("--shard", choices=["auto", "points", "buckets"], default="auto",
-                    help="N > 1: MSMs cut by point range or by bucket range (auto: buckets when the key fits)")
+                    help="N > 1: MSMs cut by point range or by bucket range (auto = points)")
     args = ap.parse_args()
 
     import torch
