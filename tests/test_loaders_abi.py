@@ -184,3 +184,28 @@ def test_wtns_and_public_inputs(gpulib, golden):
     vals = [0, 1, o.R_MOD - 1, 12345678901234567890]
     assert cc.fr_to_ints(cc.fr_from_ints(vals, gpulib), gpulib) == vals
     assert np.array_equal(cc.fr_from_ints(vals, gpulib), H.fr_mont_arr(vals))
+
+
+def test_zkey_copy_mode_survives_a_file_rewritten_under_the_handle(gpulib, golden, tmp_path):
+    """g16_zkey_open maps the file (zero-copy views; the file must stay unchanged while the handle is
+    open: include/g16_loaders.h).  G16_ZKEY_COPY=1 reads it into owned memory instead -- the key parsed
+    from a copy is still intact after the file has been truncated and rewritten."""
+    import shutil
+    import subprocess
+    src = os.path.join(golden, "test.zkey")
+    path = str(tmp_path / "copy.zkey")
+    shutil.copy(src, path)
+    code = ("import os, sys, numpy as np\n"
+            "import circom_compat_amd as cc\n"
+            "from circom_compat_amd import _binding\n"
+            f"lib = _binding.Library({gpulib.path!r})\n"
+            f"pk, mats = cc.read_zkey({path!r}, lib=lib)\n"
+            "before = pk.h_query.tobytes() + pk.a_query.tobytes()\n"
+            f"open({path!r}, 'wb').write(b'\\0' * 64)\n"             # truncate + rewrite under the open handle
+            "after = pk.h_query.tobytes() + pk.a_query.tobytes()\n"
+            f"ref, _ = cc.read_zkey(open({src!r}, 'rb').read(), lib=lib)\n"
+            "assert before == after == ref.h_query.tobytes() + ref.a_query.tobytes()\n"
+            "print('ok')\n")
+    env = dict(os.environ, G16_ZKEY_COPY="1", G16_NO_TORCH_PRELOAD="1", PYTHONPATH=os.pathsep.join(sys.path))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
