@@ -189,8 +189,9 @@ __device__ __forceinline__ void acc_way_commit(AccWay<F>& w, bool step,
 // One lane = one equal segment of the sorted entry list (persistent grid: `lanes` segments over
 // gridDim.x * blockDim.x threads, normally one each).  The dependent multiply-add chains of one
 // mixed addition cannot keep the half-rate multiplier busy on their own (~11 cycles of latency per
-// ~8-cycle issue); the two waves per SIMD its 229 VGPRs allow do (the grid of 2048 x 128 threads
-// runs as two rounds of resident workgroups; 1024 and 4096 workgroups measured slower).  Interleaving
+// ~8-cycle issue); two or three waves per SIMD do: the exact variant (219 VGPRs) runs two, the
+// optimistic G1 variant (149 VGPRs, FAST below) three -- 3072 x 128 threads = two rounds of resident
+// workgroups (msm.h, MSM_ACC_BLOCKS), the G2 kernel one wave per SIMD over 2048 workgroups.  Interleaving
 // two segments per lane in one basic block was measured and lost: ~450 VGPRs (1 wave per SIMD),
 // 21.4 vs 17.5 ms for the four G1 MSMs of a 2^22 proof; capped at 256 VGPRs it spills.
 // PS = record stride in points (2: this query is one half of an interleaved pair,
