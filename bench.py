@@ -599,6 +599,29 @@ def main():
                          "proofs": 2 * per, "in_flight": 2,
                          "what": "two ctxs sharing the point planes (g16_ctx_create_sibling), one host thread each; "
                                  "both produce the timed proof's bytes"}
+            # the same from HOST witnesses (g16_prove, what a create_proof caller hands over): each
+            # ctx's H2D runs under the other ctx's proof
+            hosts = [prover.witness_host_buffer(), sib.witness_host_buffer()]
+            for hb in hosts:
+                hb[:] = w
+
+            def worker_host(i, p):
+                torch.cuda.set_device(local_rank)
+                for _ in range(per):
+                    outs[i] = p.prove(rs[0], rs[1], hosts[i])
+
+            sib.prove(rs[0], rs[1], hosts[1])
+            torch.cuda.synchronize()
+            ths = [threading.Thread(target=worker_host, args=(i, p)) for i, p in enumerate((prover, sib))]
+            t1 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            assert outs[0].raw == proof.raw and outs[1].raw == proof.raw
+            pipelined["ms_per_proof_from_host_witness"] = dt / (2 * per) * 1e3
             sib.close()
         except Exception as e:  # noqa: BLE001 -- an extra, never the headline
             pipelined = {"error": f"{type(e).__name__}: {e}"}
