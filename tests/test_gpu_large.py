@@ -320,6 +320,43 @@ def test_full_prove_headline_sizes_bytes_pairing_and_qap_identities(gpulib, k):
         multi.close()
 
 
+def test_capacity_point_2p25_on_one_gpu(gpulib):
+    """One size above BASELINE's largest circuit: 2^25 constraints on ONE GPU -- the last size whose full
+    point planes fit 288 GB (12 planes x 384 B x 2^25 = 154 GB), window c = 22.
+    The proof passes the pairing check and a wrong public input is rejected (size-independent
+    properties); with G16_TEST_2P25_BYTES=1 the 256 bytes are also compared with the CPU restatement's
+    (about two minutes of host time: scripts/gpu_r3_run18.sh, not part of the default suite)."""
+    import torch
+    import circom_compat_amd as cc
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    import psutil
+    if torch.cuda.get_device_properties(0).total_memory < 250 * 2**30:
+        pytest.skip("needs the 288 GB of an MI355X")
+    if psutil.virtual_memory().available < 96 * 2**30:
+        pytest.skip("needs ~50 GB of host memory for the key and the witness")
+    k = 25
+    R = o.R_MOD
+    mats, (A, B, Cm), w_ints, n_vars = bench.chain_circuit(cc, k)
+    rng = random.Random(k)
+    tox = [rng.randrange(1, R) for _ in range(5)]
+    pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox)
+    rs = cc.fr_from_ints([rng.randrange(R), rng.randrange(R)])
+    w = cc.fr_from_ints(w_ints)
+    pr = cc.Prover(pk, mats)
+    info = pr.info()
+    assert info["planes_w"] == info["W_w"] and info["D_w"] == 1, "full planes must fit at 2^25: %r" % (info,)
+    proof = pr.prove(rs[0], rs[1], w)
+    assert pr.prove(rs[0], rs[1], w).raw == proof.raw
+    pr.close()
+    vk = _vk_dict(pk)
+    assert o.verify_proof(vk, [w_ints[1]], H.proof_from_bytes(proof.raw))
+    assert not o.verify_proof(vk, [(w_ints[1] + 1) % R], H.proof_from_bytes(proof.raw))
+    if os.environ.get("G16_TEST_2P25_BYTES"):
+        import cpu_ref
+        assert proof.raw == cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
+
+
 @pytest.mark.parametrize("logm,world,shard", [(14, 4, "points"), (14, 4, "buckets"), (17, 8, "buckets"),
                                               (17, 3, "buckets"), (22, 8, "points")])
 def test_in_library_multi_device_prover_large(gpulib, logm, world, shard):
