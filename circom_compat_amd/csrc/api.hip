@@ -53,18 +53,52 @@ void shard(uint32_t len, int rank, int world, uint32_t* lo, uint32_t* hi) {
   *hi = (uint32_t)((uint64_t)len * (rank + 1) / world);
 }
 
-// choose the largest number of planes that fits the memory still free on the device
-MsmConfig fit_config(size_t len, int c_over, int planes_over, size_t bytes_per_point_all_queries,
-                     size_t reserve) {
-  MsmConfig cfg = msm_make_config(len, c_over, planes_over);
-  if (planes_over > 0) return cfg;
+// work1 keeps three partial-sum slots alive (A, B1, L accumulated before one batched reduction, or
+// reduced off the main stream) for small bucket sets and sharded ranks, two otherwise
+int work1_batch(const MsmConfig& cw, uint32_t wr) {
+  return (cw.nb() / wr < (1u << 18) || wr > 1 || getenv("G16_BATCH_REDUCE")) ? 3 : 2;
+}
+
+// Device bytes the MSM state of one ctx takes for the configurations (cw: the four witness-scalar
+// queries, ch: the H query): point planes, both sorts, the partial-sum workspaces -- the same
+// arithmetic as the allocations in ctx_create_impl (MsmSort::bytes_for, msm_work_bytes).
+// own_w / own_h: false when the planes are borrowed from another ctx.
+size_t msm_state_bytes(const MsmConfig& cw, const MsmConfig& ch, uint32_t lw, uint32_t l_cnt, uint32_t lh,
+                       uint32_t wr, bool own_w, bool own_h) {
+  size_t b = 0;
+  if (own_w) b += (size_t)cw.Pn * ((size_t)lw * (64 * 2 + 128) + (size_t)l_cnt * 64);
+  if (own_h) b += (size_t)ch.Pn * lh * 64;
+  b += MsmSort::bytes_for(lw, cw) + MsmSort::bytes_for(lh, ch);
+  const uint32_t nc_w = ceil_div(cw.B, msm_red_chunk(cw, 1, wr)) * cw.D;
+  const uint32_t nc_h = ceil_div(ch.B, msm_red_chunk(ch)) * ch.D;
+  const uint32_t slots_w = cw.nb() + cw.max_lanes(), slots_h = ch.nb() + ch.max_lanes();
+  b += msm_work_bytes<Fq>(slots_w, nc_w, cw.D, work1_batch(cw, wr)) + msm_work_bytes<Fq2>(slots_w, nc_w, cw.D, 1) +
+       msm_work_bytes<Fq>(slots_h, nc_h, ch.D, 1);
+  return b;
+}
+
+// The memory plan of a ctx: full plane precomputation (D = 1: one bucket set per MSM) when it fits
+// what is free on the device, otherwise the largest plane counts that do -- the witness queries
+// (320 B per point and plane) give way first, the H query (64 B) only when they are down to one
+// plane; D > 1 bucket sets are then folded by k_horner.  Every byte the MSM state allocates is in
+// the estimate (round 3 budgeted the planes against 70 % of the free memory and nothing else);
+// what stays out is a margin of 2 GiB + 2 % for allocator granularity and the runtime's own needs.
+// Domains the reference accepts (n <= 2^27, qap.rs:30-32,63-68) are not refused for memory as long as
+// ONE plane per point fits.
+void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_t lh, uint32_t wr, bool own_w,
+                      bool own_h, MsmConfig* cw, MsmConfig* ch) {
+  if (own_w) *cw = msm_make_config(lw ? lw : 1, o.window_bits, o.planes);
+  if (own_h) *ch = msm_make_config(lh ? lh : 1, o.window_bits, o.planes);
+  if (o.planes > 0) return;  // the caller's choice: allocation failures are reported as such
   size_t fr = 0, tot = 0;
-  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return cfg;
-  const size_t budget = fr > reserve ? (size_t)((fr - reserve) * 0.7) : 0;
-  int pn = cfg.Pn;
-  while (pn > 1 && (size_t)pn * len * bytes_per_point_all_queries > budget) --pn;
-  if (pn != cfg.Pn) cfg = msm_make_config(len, c_over, pn);
-  return cfg;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return;
+  const size_t margin = ((size_t)2 << 30) + fr / 50;
+  const size_t budget = fr > margin ? fr - margin : 0;
+  while (msm_state_bytes(*cw, *ch, lw, l_cnt, lh, wr, own_w, own_h) > budget) {
+    if (own_w && cw->Pn > 1) *cw = msm_make_config(lw ? lw : 1, o.window_bits, cw->Pn - 1);
+    else if (own_h && ch->Pn > 1) *ch = msm_make_config(lh ? lh : 1, o.window_bits, ch->Pn - 1);
+    else throw std::runtime_error("the proving key does not fit this device's memory even with one plane per point");
+  }
 }
 
 void collect_times(g16_ctx* c) {
@@ -555,17 +589,6 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       c->pin_io = (uint8_t*)pin;
     }
 
-    // MSM configurations: the four witness queries share one sort, hence one (c, W, planes)
-    // what is allocated AFTER the planes comes out of the plane budget: sort state (8 + 4 bytes per
-    // entry, two sorts) and the partial-sum workspaces (up to 3 G1 slots + G2 over the witness sort,
-    // one G1 slot over the h sort), sized here with the default windows
-    size_t reserve = (size_t)3 << 30;
-    {
-      const MsmConfig ew = msm_make_config(lw ? lw : 1, o.window_bits, o.planes);
-      const MsmConfig eh = msm_make_config(lh ? lh : 1, o.window_bits, o.planes);
-      reserve += ((size_t)ew.W * lw + (size_t)eh.W * lh) * 12;
-      reserve += ((size_t)ew.nb() + ew.max_lanes()) * (144 * 3 + 288) + ((size_t)eh.nb() + eh.max_lanes()) * 144;
-    }
     g16_ctx* lender = c->share_from;
     // point planes lent by another ctx of the same key on this device (ranks of a multi-device ctx
     // that repeat a device ordinal): same configuration, views of its arrays
@@ -576,7 +599,15 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       mine.off = theirs.off;
       mine.view = theirs.data();
     };
-    c->cfg_w = lender ? lender->cfg_w : fit_config(lw ? lw : 1, o.window_bits, o.planes, 64 * 3 + 128, reserve);
+    // MSM configurations: the four witness queries share one sort, hence one (c, W, planes); both
+    // configurations are planned together against the memory that is free now (plan_msm_configs)
+    const bool lend_h = lender && c->world == 1;  // a sibling of a single-device ctx: same H planes too
+    // L pairs l_query[j] with w[num_inputs + j], i.e. entry index i = p + j
+    const uint32_t l_first = c->w_lo > c->p ? c->w_lo : c->p;  // first global entry with an L point
+    const uint32_t l_cnt = c->w_hi > l_first ? c->w_hi - l_first : 0;
+    if (lender) c->cfg_w = lender->cfg_w;
+    if (lend_h) c->cfg_h = lender->cfg_h;
+    plan_msm_configs(o, lw, l_cnt, lh, wr, !lender, !lend_h, &c->cfg_w, &c->cfg_h);
     c->sort_w.init(lw, c->cfg_w);
     c->sort_w.set_shard(c->shard_buckets ? c->rank : 0, (int)wr);
     // A and B1 are gathered by the same (scalar, digit, bucket) entries: interleaved point by point,
@@ -597,14 +628,9 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
                                  (const G1Affine*)key->b_g1_query + 1 + c->w_lo, lw, c->cfg_w, s);
       }
       c->ptsB2.init((const G2Affine*)key->b_g2_query + 1 + c->w_lo, lw, c->cfg_w, s);
-      // L pairs l_query[j] with w[num_inputs + j], i.e. entry index i = p + j
-      const uint32_t first = c->w_lo > c->p ? c->w_lo : c->p;  // first global entry with an L point
-      const uint32_t cnt = c->w_hi > first ? c->w_hi - first : 0;
-      c->l_idx_min = first - c->w_lo;
-      c->ptsL.init((const G1Affine*)key->l_query + (first - c->p), cnt, c->cfg_w, s);
+      c->l_idx_min = l_first - c->w_lo;
+      c->ptsL.init((const G1Affine*)key->l_query + (l_first - c->p), l_cnt, c->cfg_w, s);
     }
-    const bool lend_h = lender && c->world == 1;  // a sibling of a single-device ctx: same H planes too
-    c->cfg_h = lend_h ? lender->cfg_h : fit_config(lh ? lh : 1, o.window_bits, o.planes, 64, reserve);
     c->sort_h.init(lh, c->cfg_h);
     if (lend_h) {
       borrow(c->ptsH, lender->ptsH);
@@ -628,7 +654,7 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       const uint32_t nc_w = ceil_div(c->cfg_w.B, msm_red_chunk(c->cfg_w, 1, wr)) * c->cfg_w.D;
       const uint32_t nc_h = ceil_div(c->cfg_h.B, msm_red_chunk(c->cfg_h)) * c->cfg_h.D;
       const uint32_t slots_w = c->cfg_w.nb() + c->cfg_w.max_lanes(), slots_h = c->cfg_h.nb() + c->cfg_h.max_lanes();
-      c->work1.init(slots_w, nc_w, c->cfg_w.D, /*batch=*/(c->cfg_w.nb() / wr < (1u << 18) || wr > 1 || getenv("G16_BATCH_REDUCE")) ? 3 : 2);
+      c->work1.init(slots_w, nc_w, c->cfg_w.D, work1_batch(c->cfg_w, wr));
       c->workH.init(slots_h, nc_h, c->cfg_h.D, 1);
       c->work2.init(slots_w, nc_w, c->cfg_w.D);
     }

@@ -38,8 +38,12 @@ constexpr int MSM_ACC_BLOCKS_G2 = 2048; // G2: 2048 x 128 (one wave per SIMD, fo
 constexpr int MSM_MIN_SEG = 8;          // shortest per-lane segment
 constexpr int MSM_SMALL_MULTI = 32;     // buckets with <= this many partials are summed inside the reduce
 constexpr int MSM_RED_CHUNK = 16;   // max buckets per thread in the weighted bucket reduction
-constexpr uint32_t MSM_IDX_BITS = 26;
-constexpr uint32_t MSM_IDX_MASK = (1u << MSM_IDX_BITS) - 1u;
+// A sort entry packs (point index, plane, sign) into 32 bits: idx | plane << idx_bits | neg << 31.
+// MsmConfig::idx_bits = 27 (4 plane bits) whenever the configuration stores <= 16 planes -- every
+// window c >= 16, i.e. every large input: slices of up to 2^27 points, the largest domain the
+// reference accepts (Fr has two-adicity 28 and qap.rs:63-68 needs the 2n domain) -- and 26 (5 plane
+// bits, <= 32 planes) for the small windows of tiny inputs.
+constexpr uint32_t MSM_IDX_BITS_WIDE = 27, MSM_IDX_BITS_NARROW = 26;
 
 struct MsmConfig {
   int c = 0;       // window bits
@@ -47,6 +51,8 @@ struct MsmConfig {
   int Pn = 1;      // stored multiples (planes) per point
   int D = 0;       // bucket sets = ceil(W / Pn)
   uint32_t B = 0;  // buckets per set = 2^(c-1)
+  uint32_t idx_bits = MSM_IDX_BITS_NARROW;  // point-index bits of a sort entry (31 - idx_bits plane bits)
+  uint32_t max_points() const { return 1u << idx_bits; }
   uint32_t lanes = MSM_ACC_BLOCKS * MSM_ACC_THREADS;        // segments the entry list is cut into by the G1 launches
   uint32_t lanes2 = MSM_ACC_BLOCKS_G2 * MSM_ACC_THREADS;    // ... by the G2 launch over the same sort
   uint32_t nb() const { return (uint32_t)D * B; }
@@ -125,7 +131,7 @@ G16_HD uint32_t msm_seg_len(uint32_t M, uint32_t lanes) {
   return S < (uint32_t)MSM_MIN_SEG ? (uint32_t)MSM_MIN_SEG : S;
 }
 
-// Sorted (bucket -> entries) view of one scalar vector.  entry = idx | plane << 26 | neg << 31.
+// Sorted (bucket -> entries) view of one scalar vector.  entry = idx | plane << cfg.idx_bits | neg << 31.
 struct MsmSort {
   MsmConfig cfg;
   uint32_t cap = 0, len = 0;
@@ -152,6 +158,8 @@ struct MsmSort {
   // scalars: `n` field elements (Montgomery Fr when mont, else canonical U256) in device memory
   void run(const void* scalars, uint32_t n, bool mont, hipStream_t stream);
   size_t device_bytes() const;
+  // what init(capacity, cfg) allocates (the memory plan of g16_ctx_create: api.hip, plan_msm_configs)
+  static size_t bytes_for(uint32_t capacity, const MsmConfig& cfg);
 };
 
 // accumulator type of the kernels: XYZZ over the lazy 9 x 29-bit limbs (field29.h / ec29.h)
@@ -204,6 +212,13 @@ struct MsmWork {
   // sized for the larger of several sorts that will share this workspace
   void init(uint32_t n_slots, uint32_t n_contrib, int max_sets, int batch = 1);
 };
+
+// what MsmWork<F>::init(n_slots, n_contrib, max_sets, batch) allocates
+template <class F>
+inline size_t msm_work_bytes(uint32_t n_slots, uint32_t n_contrib, int max_sets, int batch) {
+  return (size_t)batch * ((size_t)n_slots + n_contrib + (size_t)257 * max_sets) * sizeof(MsmAcc<F>) +
+         (size_t)batch * sizeof(MsmFixList);
+}
 
 // out_dev[0] = sum_i scalar_i * P_{i - idx_min} over the entries of `s` with idx >= idx_min
 // (lazy internal form; finalize.hip converts to the storage form when it writes the proof).

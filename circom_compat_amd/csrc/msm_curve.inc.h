@@ -85,10 +85,11 @@ __device__ uint32_t g_gather_mask = 0xffffffffu;
 // pts already points at this query's half of an interleaved pair; PS = record stride in points
 template <class F, int PS>
 __device__ __forceinline__ void acc_fetch(const Affine<F>* __restrict__ pts, uint32_t npts,
-                                          uint32_t idx_min, uint32_t en, Affine<F>& raw) {
-  const uint32_t idx = en & MSM_IDX_MASK;
+                                          uint32_t idx_min, uint32_t idx_bits, uint32_t en,
+                                          Affine<F>& raw) {
+  const uint32_t idx = en & ((1u << idx_bits) - 1u);  // idx_bits is wave-uniform: mask and shift live in SGPRs
   if (idx >= idx_min) {
-    const uint32_t plane = (en >> MSM_IDX_BITS) & 31u;
+    const uint32_t plane = (en & 0x7fffffffu) >> idx_bits;
 #ifdef G16_DEBUG_GATHER
     raw = pts[((size_t)(plane & g_gather_mask) * npts + ((idx - idx_min) & g_gather_mask)) * PS];
 #else
@@ -102,7 +103,8 @@ __device__ __forceinline__ void acc_fetch(const Affine<F>* __restrict__ pts, uin
 template <class F, int PS>
 __device__ __forceinline__ void acc_way_init(AccWay<F>& w, uint32_t seg, uint32_t S, uint32_t M,
                                              const Affine<F>* __restrict__ pts, uint32_t npts,
-                                             uint32_t idx_min, const uint32_t* __restrict__ entries,
+                                             uint32_t idx_min, uint32_t idx_bits,
+                                             const uint32_t* __restrict__ entries,
                                              const uint32_t* __restrict__ offset, uint32_t nb) {
   w.seg = seg;
   w.pos = seg * S;
@@ -119,7 +121,7 @@ __device__ __forceinline__ void acc_way_init(AccWay<F>& w, uint32_t seg, uint32_
     w.bnext = offset[w.g + 2 < nb ? w.g + 2 : nb];
     w.en_next = entries[w.pos];
     w.en_next2 = w.pos + 1 < w.end ? entries[w.pos + 1] : 0u;
-    acc_fetch<F, PS>(pts, npts, idx_min, w.en_next, w.raw_next);
+    acc_fetch<F, PS>(pts, npts, idx_min, idx_bits, w.en_next, w.raw_next);
   }
 }
 
@@ -133,8 +135,8 @@ __device__ __forceinline__ void acc_way_init(AccWay<F>& w, uint32_t seg, uint32_
 template <class F, int PS>
 __device__ __forceinline__ Aff29<typename Lazy<F>::type> acc_way_prepare(
     AccWay<F>& w, bool* step, const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min,
-    const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset, uint32_t nb,
-    MsmAcc<F>* __restrict__ partial) {
+    uint32_t idx_bits, const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset,
+    uint32_t nb, MsmAcc<F>* __restrict__ partial) {
   using LF = typename Lazy<F>::type;
   *step = w.live && w.pos < w.end;
   const uint32_t en = w.en_next;
@@ -156,7 +158,7 @@ __device__ __forceinline__ Aff29<typename Lazy<F>::type> acc_way_prepare(
   if (*step) w.bnext = offset[w.g + 2 < nb ? w.g + 2 : nb];
   w.en_next = w.en_next2;
   if (*step && w.pos + 2 < w.end) w.en_next2 = entries[w.pos + 2];
-  if (*step && w.pos + 1 < w.end) acc_fetch<F, PS>(pts, npts, idx_min, w.en_next, w.raw_next);
+  if (*step && w.pos + 1 < w.end) acc_fetch<F, PS>(pts, npts, idx_min, idx_bits, w.en_next, w.raw_next);
   return p;
 }
 
@@ -208,9 +210,9 @@ __device__ __forceinline__ void acc_way_commit(AccWay<F>& w, bool step,
 template <class F, int PS, bool PAIR, bool FAST>
 __global__ void __launch_bounds__(ACC_THREADS) G16_ACC_ATTR
     k_bucket_accumulate(const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min,
-                        const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offset,
-                        uint32_t nb, uint32_t lanes, MsmAcc<F>* __restrict__ partial,
-                        size_t slot_stride, MsmFixList* fix) {
+                        uint32_t idx_bits, const uint32_t* __restrict__ entries,
+                        const uint32_t* __restrict__ offset, uint32_t nb, uint32_t lanes,
+                        MsmAcc<F>* __restrict__ partial, size_t slot_stride, MsmFixList* fix) {
   using LF = typename Lazy<F>::type;
   if (!FAST && fix && fix->overflow == 0) return;
   const uint32_t M = offset[nb];
@@ -226,13 +228,13 @@ __global__ void __launch_bounds__(ACC_THREADS) G16_ACC_ATTR
   }
   for (; t0 < lanes; t0 += nthreads) {
     AccWay<F> w;
-    acc_way_init<F, PS>(w, t0, S, M, pts, npts, idx_min, entries, offset, nb);
+    acc_way_init<F, PS>(w, t0, S, M, pts, npts, idx_min, idx_bits, entries, offset, nb);
     if (!w.live) break;  // segments are handed out in order: nothing left for later threads either
     for (uint32_t it = 0; it < S; ++it) {
       bool step, special;
       const uint32_t en = w.en_next;  // the entry whose point acc_way_prepare unpacks
       const Aff29<LF> p =
-          acc_way_prepare<F, PS>(w, &step, pts, npts, idx_min, entries, offset, nb, partial);
+          acc_way_prepare<F, PS>(w, &step, pts, npts, idx_min, idx_bits, entries, offset, nb, partial);
       const XYZZ29<LF> r = XYZZ29<LF>::madd_select(w.acc, p, &special);
       acc_way_commit<F, FAST>(w, step, r, special, p, en, half, fix);
     }
@@ -245,8 +247,8 @@ __global__ void __launch_bounds__(ACC_THREADS) G16_ACC_ATTR
 // filter per 2^22 MSM).  An overflowed list is left to the exact kernel: overflow = 1.
 template <class F, int PS>
 __global__ void __launch_bounds__(256)
-    k_acc_fixup(const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min, MsmFixList* fix,
-                MsmAcc<F>* partial, size_t slot_stride) {
+    k_acc_fixup(const Affine<F>* __restrict__ pts, uint32_t npts, uint32_t idx_min, uint32_t idx_bits,
+                MsmFixList* fix, MsmAcc<F>* partial, size_t slot_stride) {
   __shared__ uint32_t sl[MSM_FIX_CAP];
   __shared__ uint32_t done[MSM_FIX_CAP];
   __shared__ uint32_t left;
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(256)
       if (!first) continue;
       const uint32_t en = fix->entry[i], half = sl[i] >> 31, slot = sl[i] & 0x7fffffffu;
       Affine<F> raw;
-      acc_fetch<F, PS>(pts + half, npts, idx_min, en, raw);
+      acc_fetch<F, PS>(pts + half, npts, idx_min, idx_bits, en, raw);
       Aff29<typename Lazy<F>::type> p = load_packed_affine<F>(raw);
       if (en >> 31) p.y = p.y.neg().carry();
       MsmAcc<F>* dst = partial + (size_t)half * slot_stride + slot;
@@ -576,20 +578,20 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
     MsmFixList* fix = work.fix.p + slot;
     if (P.stride == 2)
       G16_LAUNCH((k_bucket_accumulate<F, 2, false, true>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
-                 P.count, idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+                 P.count, idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, fix);
     else
       G16_LAUNCH((k_bucket_accumulate<F, 1, false, true>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
-                 idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+                 idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, fix);
     if (tm) tm->end(id, stream);
     if (fixup) msm_fixup<F>(s, P, idx_min, work, slot, stream);
     return;
   }
   if (P.stride == 2)
     G16_LAUNCH((k_bucket_accumulate<F, 2, false, false>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
-               P.count, idx_min, en, of, nb, lanes, out, (size_t)0, (MsmFixList*)nullptr);
+               P.count, idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, (MsmFixList*)nullptr);
   else
     G16_LAUNCH((k_bucket_accumulate<F, 1, false, false>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
-               idx_min, en, of, nb, lanes, out, (size_t)0, (MsmFixList*)nullptr);
+               idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, (MsmFixList*)nullptr);
   if (tm) tm->end(id, stream);
 }
 
@@ -614,13 +616,13 @@ void msm_fixup(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWor
   // overflows the list pays for the narrow grid, nobody else.
   const uint32_t grid_x = grid < MSM_EXACT_BLOCKS ? grid : MSM_EXACT_BLOCKS;
   if (P.stride == 2) {
-    G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, P.data() + P.off, P.count, idx_min, fix, out, (size_t)0);
+    G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, P.data() + P.off, P.count, idx_min, cfg.idx_bits, fix, out, (size_t)0);
     G16_LAUNCH((k_bucket_accumulate<F, 2, false, false>), grid_x, ACC_THREADS, 0, stream, P.data() + P.off,
-               P.count, idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+               P.count, idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, fix);
   } else {
-    G16_LAUNCH((k_acc_fixup<F, 1>), 1, 256, 0, stream, P.data(), P.count, idx_min, fix, out, (size_t)0);
+    G16_LAUNCH((k_acc_fixup<F, 1>), 1, 256, 0, stream, P.data(), P.count, idx_min, cfg.idx_bits, fix, out, (size_t)0);
     G16_LAUNCH((k_bucket_accumulate<F, 1, false, false>), grid_x, ACC_THREADS, 0, stream, P.data(), P.count,
-               idx_min, en, of, nb, lanes, out, (size_t)0, fix);
+               idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, fix);
   }
 }
 
@@ -643,14 +645,14 @@ void msm_accumulate_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoint
   if constexpr (sizeof(F) == sizeof(Fq)) {
     if (acc_fast()) {
       G16_LAUNCH((k_bucket_accumulate<F, 2, true, true>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
-                 en, of, nb, cfg.lanes, out, (size_t)work.slots, work.fix.p + slot);
+                 cfg.idx_bits, en, of, nb, cfg.lanes, out, (size_t)work.slots, work.fix.p + slot);
       if (tm) tm->end(id, stream);
       if (fixup) msm_fixup_pair<F>(s, A, B, work, slot, stream);
       return;
     }
   }
   G16_LAUNCH((k_bucket_accumulate<F, 2, true, false>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
-             en, of, nb, cfg.lanes, out, (size_t)work.slots, (MsmFixList*)nullptr);
+             cfg.idx_bits, en, of, nb, cfg.lanes, out, (size_t)work.slots, (MsmFixList*)nullptr);
   if (tm) tm->end(id, stream);
 }
 
@@ -666,9 +668,9 @@ void msm_fixup_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoints<F>&
     MsmAcc<F>* out = work.partial.p + (size_t)slot * work.slots;
     MsmFixList* fix = work.fix.p + slot;
     const uint32_t grid_x = grid < MSM_EXACT_BLOCKS ? grid : MSM_EXACT_BLOCKS;  // see msm_fixup
-    G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, A.data(), A.count, 0u, fix, out, (size_t)work.slots);
+    G16_LAUNCH((k_acc_fixup<F, 2>), 1, 256, 0, stream, A.data(), A.count, 0u, cfg.idx_bits, fix, out, (size_t)work.slots);
     G16_LAUNCH((k_bucket_accumulate<F, 2, true, false>), grid_x, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
-               (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb, cfg.lanes, out,
+               cfg.idx_bits, (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb, cfg.lanes, out,
                (size_t)work.slots, fix);
   }
 }

@@ -46,10 +46,12 @@ MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
   cfg.W = (255 + c - 1) / c;
   int pn = planes_override > 0 ? planes_override : cfg.W;
   if (pn > cfg.W) pn = cfg.W;
-  if (pn > 32) pn = 32;  // 5 plane bits in an entry
+  if (pn > 32) pn = 32;  // 5 plane bits in an entry at most
+  if (len > ((size_t)1 << MSM_IDX_BITS_NARROW) && pn > 16) pn = 16;  // 27 index bits leave 4 plane bits
   cfg.D = (cfg.W + pn - 1) / pn;
   cfg.Pn = (cfg.W + cfg.D - 1) / cfg.D;
   cfg.B = 1u << (c - 1);
+  cfg.idx_bits = cfg.Pn <= 16 ? MSM_IDX_BITS_WIDE : MSM_IDX_BITS_NARROW;
   // G1 segment count: 3072 workgroups (two full rounds of the optimistic kernel's three waves per
   // SIMD) only when a segment still holds ~100 entries; with shorter segments every bucket is cut
   // into more partials than the wider grid is worth (same box: 2^22 proof 37.3 -> 37.2 ms with 3072,
@@ -100,8 +102,8 @@ struct DigitState {
   uint64_t buf = 0;
   uint32_t carry = 0;
   // window w of scalar i (the low c bits of buf): false for a zero digit
-  __device__ __forceinline__ bool take(int w, uint32_t i, int c, int D, uint32_t B, uint32_t* g,
-                                       uint32_t* entry) {
+  __device__ __forceinline__ bool take(int w, uint32_t i, int c, int D, uint32_t B, uint32_t idx_bits,
+                                       uint32_t* g, uint32_t* entry) {
     const uint32_t half = 1u << (c - 1);
     const uint32_t raw = ((uint32_t)buf & ((1u << c) - 1u)) + carry;
     buf >>= c;
@@ -118,7 +120,7 @@ struct DigitState {
     if (!mag) return false;
     const uint32_t d = (uint32_t)(w % D), j = (uint32_t)(w / D);
     *g = d * B + (mag - 1);
-    *entry = i | (j << MSM_IDX_BITS) | (neg << 31);
+    *entry = i | (j << idx_bits) | (neg << 31);
     return true;
   }
 };
@@ -126,13 +128,13 @@ struct DigitState {
 // Walks the signed c-bit digits of canonical scalar i; emit(g, entry) for every non-zero digit.
 template <class Emit>
 __device__ __forceinline__ void for_each_digit(const U256& scalar, uint32_t i, int c, int W, int D,
-                                               uint32_t B, Emit emit) {
+                                               uint32_t B, uint32_t idx_bits, Emit emit) {
   DigitState st;
   walk_windows(
       c, W, [&](int k, int avail) { st.buf |= (uint64_t)scalar.v[k] << avail; },
       [&](int w) {
         uint32_t g, e;
-        if (st.take(w, i, c, D, B, &g, &e)) emit(g, e);
+        if (st.take(w, i, c, D, B, idx_bits, &g, &e)) emit(g, e);
       });
 }
 
@@ -152,6 +154,7 @@ constexpr int P2_THREADS = 256, P2_CHUNK = 16384, P2_BINS = 4096;
 struct SortGeom {
   int c, W, D;
   uint32_t B;
+  uint32_t idx_bits;  // MsmConfig::idx_bits
   int sh;          // partition = bucket >> sh
   uint32_t bins1;  // number of partitions
 };
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_count(const void* scalars, 
       const uint32_t i = tile * P1_TILE + k * P1_THREADS + tid;
       if (i >= n) continue;
       const U256 sc = load_scalar<MONT>(scalars, i);
-      for_each_digit(sc, i, G.c, G.W, G.D, G.B, [&](uint32_t g, uint32_t) { atomicAdd(&h[g >> G.sh], 1u); });
+      for_each_digit(sc, i, G.c, G.W, G.D, G.B, G.idx_bits, [&](uint32_t g, uint32_t) { atomicAdd(&h[g >> G.sh], 1u); });
     }
   }
   __syncthreads();
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
             bool v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-              v[u] = wk[u].take(w, idx[k0 + u], G.c, G.D, G.B, &g[u], &e[u]) && live[k0 + u];
+              v[u] = wk[u].take(w, idx[k0 + u], G.c, G.D, G.B, G.idx_bits, &g[u], &e[u]) && live[k0 + u];
               if (v[u]) {
                 const uint32_t pb = g[u] >> G.sh;
                 v[u] = pb >= p_lo && pb < p_hi;
@@ -518,7 +521,10 @@ void MsmSort::set_shard(int rank_, int world_) {
 void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   cfg = c;
   cap = capacity;
-  if (capacity > MSM_IDX_MASK) throw std::runtime_error("MSM slice too large (2^26 points max)");
+  // an entry holds idx_bits index bits and 31 - idx_bits plane bits (msm.h); 2^27 points is also the
+  // largest domain the reference accepts (witness_map.hip: PolynomialDegreeTooLarge above it)
+  if (capacity > cfg.max_points() || (uint32_t)cfg.Pn > (1u << (31 - cfg.idx_bits)))
+    throw std::runtime_error("MSM slice does not fit the sort entry (2^27 points x 16 planes, or 2^26 x 32)");
   const uint32_t nb = cfg.nb();
   const uint64_t M = (uint64_t)cap * cfg.W;
   if (M >= ((uint64_t)1 << 32)) throw std::runtime_error("MSM entry count exceeds 2^32");
@@ -539,6 +545,15 @@ void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   scan_tmp.alloc(ceil_div(scan_len, SCAN_TILE) + 1);
 }
 
+size_t MsmSort::bytes_for(uint32_t capacity, const MsmConfig& cfg) {
+  const uint64_t M = std::max<uint64_t>((uint64_t)capacity * cfg.W, 1);
+  const uint64_t nb = cfg.nb();
+  const uint64_t hist = (uint64_t)P1_MAX_BINS * sort_grid_cap() + 1;
+  const uint64_t large = M / ((uint64_t)MSM_MIN_SEG * MSM_SMALL_MULTI) + 2;
+  return (size_t)(M * sizeof(MsmPair) + M * 4 + 3 * (nb + 1) * 4 + 2 * hist * 4 + 2 * large * 4 +
+                  (ceil_div(std::max<uint64_t>(nb + 1, hist), SCAN_TILE) + 1) * 4 + (P1_MAX_BINS + 1) * 4 + 64);
+}
+
 size_t MsmSort::device_bytes() const {
   return part.bytes() + count.bytes() + offset.bytes() + cursor.bytes() + entries.bytes() +
          multi_l.bytes();
@@ -553,6 +568,7 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
   G.W = cfg.W;
   G.D = cfg.D;
   G.B = cfg.B;
+  G.idx_bits = cfg.idx_bits;
   G.sh = msm_part_shift(nb);
   G.bins1 = ((nb - 1) >> G.sh) + 1;
   G16_HIP(hipMemsetAsync(count.p, 0, ((size_t)nb + 1) * 4, s));

@@ -129,4 +129,10 @@ static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = 0) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
-static inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = *t = (size_t)1 << 34; return hipSuccess; }
+// G16_EMU_FREE_BYTES (tests only): the free device memory the emulator reports -- lets the CPU suite
+// drive the ctx's memory plan (api.hip, plan_msm_configs) into its fewer-planes fallback
+static inline hipError_t hipMemGetInfo(size_t* f, size_t* t) {
+  const char* e = getenv("G16_EMU_FREE_BYTES");
+  *f = *t = e ? (size_t)strtoull(e, nullptr, 0) : (size_t)1 << 34;
+  return hipSuccess;
+}

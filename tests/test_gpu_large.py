@@ -357,6 +357,76 @@ def test_capacity_point_2p25_on_one_gpu(gpulib):
         assert proof.raw == cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
 
 
+def test_fewer_planes_than_windows_2p22_bytes(gpulib):
+    """The fallback every domain above the full-plane capacity point (2^25) runs on -- planes < W, D > 1
+    bucket sets per MSM folded by k_horner with c doublings in between -- on the REAL kernels at the
+    headline size: 2^22 with planes = 4 (W = 13 -> D = 4: 2^21 buckets, four reductions folded per MSM),
+    and planes = 1 on the H query's own sort (D = W).  Bytes == the CPU restatement's proof."""
+    import circom_compat_amd as cc
+    import cpu_ref
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    k = 22
+    R = o.R_MOD
+    mats, (A, B, Cm), w_ints, n_vars = bench.chain_circuit(cc, k)
+    rng = random.Random(k + 400)
+    tox = [rng.randrange(1, R) for _ in range(5)]
+    pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox)
+    rs = cc.fr_from_ints([rng.randrange(R), rng.randrange(R)])
+    w = cc.fr_from_ints(w_ints)
+    want = cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
+    for planes in (4, 1):
+        pr = cc.Prover(pk, mats, planes=planes)
+        info = pr.info()
+        assert info["planes_w"] == planes and info["D_w"] == -(-info["W_w"] // planes) and info["D_w"] > 1, info
+        assert info["planes_h"] == planes and info["D_h"] > 1, info
+        got = pr.prove(rs[0], rs[1], w)
+        pr.close()
+        assert got.raw == want, "planes=%d (D=%d) proof differs from the CPU restatement" % (planes, info["D_w"])
+    assert o.verify_proof(_vk_dict(pk), [w_ints[1]], H.proof_from_bytes(got.raw))
+
+
+def test_domain_2p26_on_one_gpu_not_refused(gpulib):
+    """A domain the reference accepts (qap.rs:30-32,63-68: any n with a 2n-th root of unity, n <= 2^27)
+    must not be refused: 2^26 constraints on ONE GPU -- past the size whose full point planes fit 288 GB,
+    so plan_msm_configs (api.hip) picks planes < W for the witness queries.  Opt-in (G16_TEST_2P26=1:
+    ~35 GB of host memory for the key, several minutes; scripts/r4_chain26.sh runs it once per round and
+    keeps the log under profiles/): pairing check, wrong input rejected, and with
+    G16_TEST_2P26_BYTES=1 the 256 bytes against the CPU restatement."""
+    if not os.environ.get("G16_TEST_2P26"):
+        pytest.skip("opt-in: G16_TEST_2P26=1")
+    import torch
+    import circom_compat_amd as cc
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    import psutil
+    if torch.cuda.get_device_properties(0).total_memory < 250 * 2**30:
+        pytest.skip("needs the 288 GB of an MI355X")
+    if psutil.virtual_memory().available < 160 * 2**30:
+        pytest.skip("needs ~100 GB of host memory for the key, the matrices and the witness")
+    k = 26
+    R = o.R_MOD
+    mats, (A, B, Cm), w_ints, n_vars = bench.chain_circuit(cc, k)
+    rng = random.Random(k)
+    tox = [rng.randrange(1, R) for _ in range(5)]
+    pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox)
+    rs = cc.fr_from_ints([rng.randrange(R), rng.randrange(R)])
+    w = cc.fr_from_ints(w_ints)
+    pr = cc.Prover(pk, mats)
+    info = pr.info()
+    print("2^26 configuration:", info)
+    assert info["domain_size"] == 1 << k and info["D_w"] > 1, info
+    proof = pr.prove(rs[0], rs[1], w)
+    assert pr.prove(rs[0], rs[1], w).raw == proof.raw
+    pr.close()
+    vk = _vk_dict(pk)
+    assert o.verify_proof(vk, [w_ints[1]], H.proof_from_bytes(proof.raw))
+    assert not o.verify_proof(vk, [(w_ints[1] + 1) % R], H.proof_from_bytes(proof.raw))
+    if os.environ.get("G16_TEST_2P26_BYTES"):
+        import cpu_ref
+        assert proof.raw == cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
+
+
 @pytest.mark.parametrize("logm,world,shard", [(14, 4, "points"), (14, 4, "buckets"), (17, 8, "buckets"),
                                               (17, 3, "buckets"), (22, 8, "points")])
 def test_in_library_multi_device_prover_large(gpulib, logm, world, shard):

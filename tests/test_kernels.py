@@ -229,6 +229,62 @@ def test_prove_synthetic_circuit_vs_oracle(lib):
     assert p2.prove_finish(r, s, parts).raw == proof.raw
 
 
+def test_memory_plan_falls_back_to_fewer_planes_instead_of_refusing(emu, monkeypatch):
+    """g16_ctx_create plans both MSM configurations against the free device memory (api.hip,
+    plan_msm_configs): full planes when they fit, otherwise the witness queries give planes away first
+    (D > 1 bucket sets folded by k_horner), and only a key for which no plane count fits is refused,
+    with the reason.  The emulator reports whatever G16_EMU_FREE_BYTES says, so the test walks the free
+    memory up from the refusal threshold and checks that every configuration on the way proves the
+    oracle's bytes.  (At this toy size every extra bucket set costs more workspace than a plane of 126
+    points saves, so the walk ends at 16 planes; at 2^26 a plane is 21 GB and a bucket set 1.5 GB.)"""
+    import circom_compat_amd as cc
+    cons, w, n_vars, n_pub = H.squaring_chain(7)
+    rng = random.Random(77)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    opk = o.trapdoor_setup(cons, n_vars, n_pub, *tox)
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, emu)
+    pk = H.pk_from_oracle(opk)
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    want = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2, len(cons), w))
+    WB = 4                       # W = 64 windows -> 32 planes at most, 40 KB per plane of the witness queries
+
+    def create(extra):           # the plan keeps 2 GiB + 2 % of the free memory out of its budget
+        monkeypatch.setenv("G16_EMU_FREE_BYTES", str(int(((2 << 30) + extra) / 0.98)))
+        try:
+            return cc.Prover(pk, mats, lib=emu, window_bits=WB)
+        except Exception as e:
+            assert "does not fit" in str(e), e
+            return None
+
+    lo, hi = 0, 16 << 10         # smallest `extra` (KiB) that is not refused
+    while lo < hi:
+        mid = (lo + hi) // 2
+        pr = create(mid << 10)
+        if pr is not None:
+            pr.close()
+        lo, hi = (lo, mid) if pr is not None else (mid + 1, hi)
+    t_min = lo << 10
+    assert t_min > 0 and create(t_min - 1024) is None, "a key that cannot fit is refused, with the reason"
+    seen = {}
+    for j in range(16):
+        pr = create(t_min + j * (96 << 10))
+        info = pr.info()
+        key = (info["planes_w"], info["planes_h"])
+        if key not in seen:
+            seen[key] = info
+            assert info["D_w"] == -(-info["W_w"] // info["planes_w"]) and info["D_h"] == -(-info["W_h"] // info["planes_h"])
+            assert pr.prove(r, s, w).raw == want, "planes %r: proof differs from the oracle" % (key,)
+        pr.close()
+        if key == (32, 32):
+            break
+    monkeypatch.delenv("G16_EMU_FREE_BYTES")
+    assert (32, 32) in seen, sorted(seen)
+    reduced = [k for k in seen if k[0] < 32]
+    assert len(reduced) >= 2 and all(ph == 32 for _, ph in reduced), \
+        "the witness queries (320 B per point and plane) give planes away first: %r" % (sorted(seen),)
+
+
 def test_trapdoor_setup_vs_oracle(lib):
     """GPU key generator (g16_setup_create) == oracle trapdoor setup, point for point; the key then
     proves and the proof verifies.  Mirrors reference tests/groth16.rs:11-40 (setup -> prove ->
