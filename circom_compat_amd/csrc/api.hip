@@ -124,6 +124,11 @@ void fixup_ab(g16_ctx* c, hipStream_t q) {
   }
 }
 
+int defer_l_red() {
+  static const int v = [] { const char* e = getenv("G16_DEFER_L_RED"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 // main stream: witness-scalar sort, then the A, B1, L, B2 MSMs (ALU bound).  `after_ab` is called
 // once the A and B1 sums are enqueued: the provers fork the variable-base part of the
 // finalisation onto the side stream there.
@@ -140,6 +145,7 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
   hipStream_t s = c->stream;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   ProofSums* S = c->sums_dev.p;
+  c->l_red_deferred = 0;
   if (!sorted) enqueue_witness_sort(c, w_dev);
   // A/B knobs (measurement only): G16_BATCH_REDUCE / G16_B2_RED_STREAM = 0 | 1 override the size rules
   static const int knob_batch = [] { const char* e = getenv("G16_BATCH_REDUCE"); return e ? atoi(e) : -1; }();
@@ -207,7 +213,13 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     accumulate_ab(c, s, tm);
     msm_reduce<Fq>(c->sort_w, c->work1, 0, 2, &S->A, s, tm);  // ProofSums keeps A, B1 adjacent
     after_ab(s);
-    msm_run<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, &S->L, s, tm);
+    // G16_DEFER_L_RED (round-4 experiment): the L reduction leaves the main stream.
+    // 1: it starts on `red` when the B2 reduction is through, i.e. beside the H accumulation;
+    // 2: it starts when the H accumulation is through, beside the H reduction (two single-wave chains
+    //    per SIMD, both latency bound).  Its partials stay in work1 slot 0, which nothing reuses.
+    c->l_red_deferred = c->overlap ? defer_l_red() : 0;
+    if (c->l_red_deferred) msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 0, s, tm);
+    else msm_run<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, &S->L, s, tm);
   }
   // B2: accumulate here; with small bucket sets its reduction (a latency-bound chain of Fq2 point
   // additions) runs on its own stream underneath the H MSM -- with large ones it only takes VALU
@@ -226,6 +238,8 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
   G16_HIP(hipEventRecord(c->ev_b2, rs));
   if (rs != c->red) G16_HIP(hipStreamWaitEvent(c->red, c->ev_b2, 0));
   after_b2();
+  if (c->l_red_deferred == 1) msm_reduce<Fq>(c->sort_w, c->work1, 0, 1, &S->L, c->red, tm, /*hidden=*/true);
+  if (c->l_red_deferred == 2) return;  // enqueue_h_msm finishes the fork/join once the H accumulation is enqueued
   G16_HIP(hipEventRecord(c->ev_b2, c->red));
   G16_HIP(hipStreamWaitEvent(c->side, c->ev_b2, 0));  // the side stream joins it: one event to wait on
   G16_HIP(hipEventRecord(c->ev_side, c->side));
@@ -238,6 +252,19 @@ void enqueue_h_msm(g16_ctx* c) {
   hipStream_t s = c->stream;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   G16_HIP(hipStreamWaitEvent(s, c->ev_h, 0));
+  if (c->l_red_deferred == 2) {
+    c->l_red_deferred = 0;
+    msm_accumulate<Fq>(c->sort_h, c->ptsH, 0, c->workH, 0, s, tm);
+    G16_HIP(hipEventRecord(c->ev_acc[2], s));
+    G16_HIP(hipStreamWaitEvent(c->red, c->ev_acc[2], 0));
+    msm_reduce<Fq>(c->sort_w, c->work1, 0, 1, &c->sums_dev.p->L, c->red, tm);
+    G16_HIP(hipEventRecord(c->ev_b2, c->red));
+    G16_HIP(hipStreamWaitEvent(c->side, c->ev_b2, 0));
+    G16_HIP(hipEventRecord(c->ev_side, c->side));
+    msm_reduce<Fq>(c->sort_h, c->workH, 0, 1, &c->sums_dev.p->H, s, tm);
+    return;
+  }
+  c->l_red_deferred = 0;
   msm_run<Fq>(c->sort_h, c->ptsH, 0, c->workH, &c->sums_dev.p->H, s, tm);
 }
 

@@ -24,6 +24,7 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
 #include <functional>
 #include <vector>
 
@@ -216,18 +217,29 @@ uint32_t enable_peers(const std::vector<g16_ctx*>& ch, std::string* why) {
   return state;
 }
 
+// G16_DEBUG_SELFTEST_CORRUPT="x:src:dst" (tests only): the create-time self-test's copy of exchange x
+// (0, 1; 2 = the record gather) from rank src to rank dst reads the wrong source chunk -- what a
+// misrouted peer copy would deliver.  tests/test_kernels.py checks that g16_ctx_create_multi then fails.
+bool selftest_corrupt(int x, int src, int dst) {
+  const char* e = getenv("G16_DEBUG_SELFTEST_CORRUPT");
+  int cx = -1, cs = -1, cd = -1;
+  return e && sscanf(e, "%d:%d:%d", &cx, &cs, &cd) == 3 && cx == x && cs == src && cd == dst;
+}
+
 // exchange x of rank g: its G chunks go to the G recv buffers (own chunk included), each on its
-// own stream behind the producer's ev_send
-void push_chunks(Multi& M, int g, int x) {
+// own stream behind the producer's ev_send.  ints < chunk_ints: only the head of every chunk (the
+// create-time self-test); selftest: the corruption hook above applies.
+void push_chunks(Multi& M, int g, int x, size_t ints = 0, bool selftest = false) {
   g16_ctx* c = M.ch[g];
   Multi::Dev& me = *M.dv[g];
-  const size_t bytes = M.chunk_ints * sizeof(int32_t);
+  const size_t bytes = (ints ? ints : M.chunk_ints) * sizeof(int32_t);
   for (int k = 0; k < M.G; ++k) {
     const int d = (g + k) % M.G;  // start with the own chunk, then rotate: no destination is hit by all at once
     hipStream_t st = me.cs[d];
+    const int from = selftest && selftest_corrupt(x, g, d) ? (d + 1) % M.G : d;
     G16_HIP(hipStreamWaitEvent(st, c->ev_send, 0));
     G16_HIP(hipMemcpyPeerAsync(M.dv[d]->recv[x].p + (size_t)g * M.chunk_ints, M.ch[d]->device,
-                               me.send[x].p + (size_t)d * M.chunk_ints, c->device, bytes, st));
+                               me.send[x].p + (size_t)from * M.chunk_ints, c->device, bytes, st));
     G16_HIP(hipEventRecord(me.arrived[x][d], st));
   }
 }
@@ -238,6 +250,133 @@ void await_chunks(Multi& M, int g, int x, hipStream_t consumer) {
 }
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+// ---- create-time self-test of the peer paths --------------------------------------------------
+// A proof's exchanges are peer copies and cross-device event waits that nothing on a single-GPU box
+// ever executes between two DISTINCT devices.  So g16_ctx_create_multi runs one small all-to-all
+// echo through exactly the code a proof uses -- push_chunks / await_chunks on the aux stream behind
+// ev_send, both exchange buffers, every (source, destination) pair incl. the local one -- and one
+// gather of the 1 KiB partial records to the first device behind ev_part, all with known patterns:
+// a broken or misrouted peer path is an error at create (naming the pair), not a wrong proof later.
+namespace {
+
+constexpr uint32_t ST_WORDS = 1024;   // 4 KiB per (source, destination) pair
+constexpr uint32_t ST_ECHO = 0x5a5a5a5au;
+
+__host__ __device__ inline uint32_t selftest_word(uint32_t src, uint32_t dst, uint32_t i, uint32_t salt) {
+  uint32_t x = (src + 1u) * 0x9e3779b1u ^ (dst + 1u) * 0x85ebca77u ^ (i + 1u) * 0xc2b2ae3du ^ salt;
+  x ^= x >> 15;
+  x *= 0x2c1b3c6du;
+  x ^= x >> 12;
+  return x;
+}
+
+// buf[d * stride + i] = word(me, d, i) for d < G, i < T
+__global__ void __launch_bounds__(256) k_selftest_fill(int32_t* buf, size_t stride, uint32_t T, uint32_t G,
+                                                       uint32_t me, uint32_t salt) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G * T) return;
+  const uint32_t d = idx / T, i = idx % T;
+  buf[(size_t)d * stride + i] = (int32_t)selftest_word(me, d, i, salt);
+}
+
+// mode 0: recv[src * stride + i] must be word(src, me, i); the echo send2[src * stride + i] = that ^ ST_ECHO
+// mode 1: recv[src * stride + i] must be word(me, src, i) ^ ST_ECHO (my own words, back from src)
+// mode 2: recv[src * stride + i] must be word(src, 0, i) (the gathered records)
+// bad[src] counts the mismatching words of source src
+__global__ void __launch_bounds__(256) k_selftest_check(const int32_t* recv, int32_t* send2, size_t stride, uint32_t T,
+                                                        uint32_t G, uint32_t me, uint32_t salt, int mode,
+                                                        uint32_t* bad) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G * T) return;
+  const uint32_t src = idx / T, i = idx % T;
+  const uint32_t got = (uint32_t)recv[(size_t)src * stride + i];
+  uint32_t want;
+  if (mode == 0) want = selftest_word(src, me, i, salt);
+  else if (mode == 1) want = selftest_word(me, src, i, salt) ^ ST_ECHO;
+  else want = selftest_word(src, 0u, i, salt);
+  if (got != want) atomicAdd(&bad[src], 1u);
+  if (mode == 0) send2[(size_t)src * stride + i] = (int32_t)(got ^ ST_ECHO);
+}
+
+void multi_selftest(Multi& M) {
+  const int G = M.G;
+  const uint32_t T = M.dist ? (uint32_t)std::min<size_t>(M.chunk_ints, ST_WORDS) : 0u;
+  const uint32_t TR = G16_PARTIAL_BYTES / 4;  // one partial record
+  const uint32_t salt = 0x67313661u;
+  std::vector<std::unique_ptr<DevBuf<uint32_t>>> bad;
+  for (int g = 0; g < G; ++g) bad.emplace_back(new DevBuf<uint32_t>());
+  std::vector<std::vector<uint32_t>> host(G, std::vector<uint32_t>(3 * (size_t)G, 0u));
+  std::vector<std::function<void(int)>> st;
+  st.push_back([&](int g) {
+    g16_ctx* c = M.ch[g];
+    G16_HIP(hipSetDevice(c->device));
+    bad[g]->alloc(3 * (size_t)G);
+    G16_HIP(hipMemsetAsync(bad[g]->p, 0, 3 * (size_t)G * 4, c->aux));
+    if (T)
+      G16_LAUNCH(k_selftest_fill, ceil_div((uint64_t)G * T, 256), 256, 0, c->aux, M.dv[g]->send[0].p, M.chunk_ints, T,
+                 (uint32_t)G, (uint32_t)g, salt);
+    G16_HIP(hipEventRecord(c->ev_send, c->aux));
+    if (T) push_chunks(M, g, 0, T, /*selftest=*/true);
+    // this rank's "partial record": the pattern word(g, 0, i), complete behind ev_part on the main stream
+    G16_HIP(hipStreamWaitEvent(c->stream, c->ev_send, 0));
+    G16_LAUNCH(k_selftest_fill, ceil_div(TR, 256), 256, 0, c->stream, (int32_t*)c->part_dev(), (size_t)TR, TR, 1u,
+               (uint32_t)g, salt ^ 2u);
+    G16_HIP(hipEventRecord(c->ev_part, c->stream));
+  });
+  if (T)
+    st.push_back([&](int g) {
+      g16_ctx* c = M.ch[g];
+      G16_HIP(hipSetDevice(c->device));
+      await_chunks(M, g, 0, c->aux);
+      G16_LAUNCH(k_selftest_check, ceil_div((uint64_t)G * T, 256), 256, 0, c->aux, (const int32_t*)M.dv[g]->recv[0].p,
+                 M.dv[g]->send[1].p, M.chunk_ints, T, (uint32_t)G, (uint32_t)g, salt, 0, bad[g]->p);
+      G16_HIP(hipEventRecord(c->ev_send, c->aux));
+      push_chunks(M, g, 1, T, /*selftest=*/true);
+    });
+  st.push_back([&](int g) {
+    g16_ctx* c = M.ch[g];
+    G16_HIP(hipSetDevice(c->device));
+    if (T) {
+      await_chunks(M, g, 1, c->aux);
+      G16_LAUNCH(k_selftest_check, ceil_div((uint64_t)G * T, 256), 256, 0, c->aux, (const int32_t*)M.dv[g]->recv[1].p,
+                 (int32_t*)nullptr, M.chunk_ints, T, (uint32_t)G, (uint32_t)g, salt, 1, bad[g]->p + G);
+    }
+    if (g == 0) {  // the record gather of stage_gather_finish, checked instead of summed
+      hipStream_t s = c->stream;
+      for (int src = 0; src < G; ++src) {
+        G16_HIP(hipStreamWaitEvent(s, M.ch[src]->ev_part, 0));
+        const size_t off = selftest_corrupt(2, src, 0) ? 4 : 0;
+        G16_HIP(hipMemcpyPeerAsync(c->gathered_dev() + (size_t)src * G16_PARTIAL_BYTES, c->device,
+                                   M.ch[src]->part_dev() + off, M.ch[src]->device, G16_PARTIAL_BYTES - off, s));
+      }
+      G16_HIP(hipStreamWaitEvent(s, c->ev_send, 0));  // bad[] was zeroed on aux
+      G16_LAUNCH(k_selftest_check, ceil_div((uint64_t)G * TR, 256), 256, 0, s, (const int32_t*)c->gathered_dev(),
+                 (int32_t*)nullptr, (size_t)TR, TR, (uint32_t)G, 0u, salt ^ 2u, 2, bad[0]->p + 2 * G);
+      G16_HIP(hipStreamSynchronize(s));
+    }
+    G16_HIP(hipStreamSynchronize(c->aux));
+    G16_HIP(hipMemcpy(host[g].data(), bad[g]->p, 3 * (size_t)G * 4, hipMemcpyDeviceToHost));
+    // leave the buffers as a fresh ctx has them
+    G16_HIP(hipMemsetAsync(c->out_dev.p, 0, c->out_dev.bytes(), c->stream));
+    G16_HIP(hipStreamSynchronize(c->stream));
+    bad[g]->release();
+  });
+  const int code = M.pool.run(st);
+  if (code != G16_OK) throw std::runtime_error("multi-device self-test: " + M.pool.first_error);
+  static const char* what[3] = {"all-to-all exchange 0", "all-to-all exchange 1 (echo)", "partial-record gather"};
+  for (int x = 0; x < 3; ++x)  // the earliest failing stage first: a bad exchange 0 also spoils its echo
+    for (int g = 0; g < G; ++g)
+      for (int src = 0; src < G; ++src)
+        if (host[g][(size_t)x * G + src])
+          throw std::runtime_error(std::string("multi-device self-test failed: ") + what[x] + ", rank " + std::to_string(src) +
+                                   " (device " + std::to_string(M.ch[src]->device) + ") -> rank " + std::to_string(g) +
+                                   " (device " + std::to_string(M.ch[g]->device) + "): " +
+                                   std::to_string(host[g][(size_t)x * G + src]) + " words differ -- the peer path between these devices "
+                                   "does not deliver what was sent");
+}
 
 }  // namespace
 
@@ -371,6 +510,7 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
       if (peer_state != 1 && req && atoi(req) != 0) throw std::runtime_error("G16_REQUIRE_PEER_ACCESS: " + why);
       if (peer_state != 1)
         fprintf(stderr, "libg16_amd: %s -- the exchanges of every proof will be staged by the runtime\n", why.c_str());
+      multi_selftest(*M);
     } catch (const std::exception& e) {
       code = G16_ERR_HIP;
       M->pool.first_error = e.what();

@@ -450,14 +450,15 @@ def h_query_scalars_libsnark(max_power, t, zt, delta_inverse):
     return [zt * delta_inverse % R_MOD * pow(t, i, R_MOD) % R_MOD for i in range(max_power)]
 
 
-def h_query_scalars(max_power, t, delta_inverse):
-    """reference src/circom/qap.rs:90-105."""
+def h_query_scalars(max_power, t, delta_inverse, ntt_fn=None):
+    """reference src/circom/qap.rs:90-105.  ntt_fn: another (pinned) implementation of ntt() for the
+    one transform of size 2n (tests at 2^16 .. 2^20 pass the C restatement's FFT)."""
     scalars = [delta_inverse * pow(t, i, R_MOD) % R_MOD for i in range(2 * max_power + 1)]
     size = domain_size_for(len(scalars))
     if size is None:
         raise ValueError("PolynomialDegreeTooLarge")
     scalars = scalars + [0] * (size - len(scalars))            # ifft_in_place resizes to the domain
-    scalars = ntt(scalars, inverse=True)
+    scalars = (ntt_fn or ntt)(scalars, inverse=True)
     return scalars[1::2]
 
 
@@ -816,21 +817,24 @@ def verify_proof(vk, public_inputs, proof):
 # trapdoor (known-tau) circom/snarkjs-style setup -- used to mint synthetic keys for tests
 # (SURVEY.md Appendix C.2).  Not part of the reference's proving path.
 # ----------------------------------------------------------------------------------------------
-def lagrange_at_tau(n, tau):
+def lagrange_at_tau(n, tau, ntt_fn=None):
     """L_j(tau) for the size-n domain = inverse DFT of the powers of tau."""
-    return ntt([pow(tau, i, R_MOD) for i in range(n)], inverse=True)
+    pw = [1] * n
+    for i in range(1, n):
+        pw[i] = pw[i - 1] * tau % R_MOD
+    return (ntt_fn or ntt)(pw, inverse=True)
 
 
-def trapdoor_setup(constraints, n_vars, n_public, tau, alpha, beta, gamma, delta, reduction="circom"):
-    """constraints: list of (A,B,C) rows, each a list of (wire, coeff) as in the .r1cs file.
-    Returns a pk dict shaped like read_zkey's (plus the scalar-side trapdoor data under 'td').
-    reduction: "circom" (CircomReduction::h_query_scalars, qap.rs:90-105) or "libsnark" (arkworks'
-    default QAP, reference tests/groth16.rs:25); the libsnark H query has n - 1 entries and is
-    padded with the point at infinity to n."""
+def trapdoor_scalars(constraints, n_vars, n_public, tau, alpha, beta, gamma, delta, reduction="circom",
+                     ntt_fn=None):
+    """The scalar side of the trapdoor setup: every query point of the key is k * G for the k returned
+    here (u -> a_query, v -> b_g1_query / b_g2_query, k_l -> l_query, k_h -> h_query, k_ic -> vk.ic).
+    O(n log n) field operations and no group operation, so tests can pin a key generator at sizes
+    where forming the points in Python would take minutes (ntt_fn: see h_query_scalars)."""
     m = len(constraints)
     num_inputs = n_public + 1
     n = domain_size_for(m + num_inputs)
-    L = lagrange_at_tau(n, tau)
+    L = lagrange_at_tau(n, tau, ntt_fn)
     u = [0] * n_vars
     v = [0] * n_vars
     w = [0] * n_vars
@@ -850,19 +854,30 @@ def trapdoor_setup(constraints, n_vars, n_public, tau, alpha, beta, gamma, delta
         zt = (pow(tau, n, R_MOD) - 1) % R_MOD
         k_h = h_query_scalars_libsnark(n - 1, tau, zt, di) + [0]
     else:
-        k_h = h_query_scalars(n - 1, tau, di)
+        k_h = h_query_scalars(n - 1, tau, di, ntt_fn)
+    return dict(u=u, v=v, w=w, k_l=k_l, k_h=k_h, k_ic=k_ic, tau=tau, alpha=alpha, beta=beta, gamma=gamma,
+                delta=delta, domain_size=n)
+
+
+def trapdoor_setup(constraints, n_vars, n_public, tau, alpha, beta, gamma, delta, reduction="circom"):
+    """constraints: list of (A,B,C) rows, each a list of (wire, coeff) as in the .r1cs file.
+    Returns a pk dict shaped like read_zkey's (plus the scalar-side trapdoor data under 'td').
+    reduction: "circom" (CircomReduction::h_query_scalars, qap.rs:90-105) or "libsnark" (arkworks'
+    default QAP, reference tests/groth16.rs:25); the libsnark H query has n - 1 entries and is
+    padded with the point at infinity to n."""
+    td = trapdoor_scalars(constraints, n_vars, n_public, tau, alpha, beta, gamma, delta, reduction)
+    n = td.pop("domain_size")
     g1m = lambda k: G1.mul(G1_GEN, k)
     g2m = lambda k: G2.mul(G2_GEN, k)
     pk = dict(
         q=Q_MOD, r=R_MOD, n_vars=n_vars, n_public=n_public, domain_size=n,
         alpha_g1=g1m(alpha), beta_g1=g1m(beta), beta_g2=g2m(beta), gamma_g2=g2m(gamma),
         delta_g1=g1m(delta), delta_g2=g2m(delta),
-        ic=[g1m(k) for k in k_ic],
-        a_query=[g1m(k) for k in u], b_g1_query=[g1m(k) for k in v],
-        b_g2_query=[g2m(k) for k in v], l_query=[g1m(k) for k in k_l],
-        h_query=[g1m(k) for k in k_h],
-        td=dict(u=u, v=v, w=w, k_l=k_l, k_h=k_h, k_ic=k_ic, tau=tau, alpha=alpha, beta=beta,
-                gamma=gamma, delta=delta),
+        ic=[g1m(k) for k in td["k_ic"]],
+        a_query=[g1m(k) for k in td["u"]], b_g1_query=[g1m(k) for k in td["v"]],
+        b_g2_query=[g2m(k) for k in td["v"]], l_query=[g1m(k) for k in td["k_l"]],
+        h_query=[g1m(k) for k in td["k_h"]],
+        td=td,
     )
     return pk
 

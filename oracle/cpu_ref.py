@@ -127,6 +127,33 @@ def prove(pk, mats, r_mont, s_mont, w, want_h=False, reduction="circom"):
     return (out.tobytes(), h) if want_h else out.tobytes()
 
 
+def _canon_arr(ks):
+    a = np.zeros((len(ks), 4), dtype=np.uint64)
+    for i, k in enumerate(ks):
+        for j in range(4):
+            a[i, j] = (k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return a
+
+
+def g1_mul_batch(point_bytes, ks):
+    """[k * P for k in ks] as 64-byte packed affine points (P: 64 bytes, ks: ints < r)"""
+    a = _canon_arr(ks)
+    out = np.empty((len(ks), 64), dtype=np.uint8)
+    p = np.frombuffer(bytes(point_bytes), dtype=np.uint8).copy()
+    lib().g16cpu_g1_mul_batch(C.c_void_p(p.ctypes.data), C.c_void_p(a.ctypes.data), C.c_size_t(len(ks)),
+                              C.c_void_p(out.ctypes.data))
+    return out
+
+
+def g2_mul_batch(point_bytes, ks):
+    a = _canon_arr(ks)
+    out = np.empty((len(ks), 128), dtype=np.uint8)
+    p = np.frombuffer(bytes(point_bytes), dtype=np.uint8).copy()
+    lib().g16cpu_g2_mul_batch(C.c_void_p(p.ctypes.data), C.c_void_p(a.ctypes.data), C.c_size_t(len(ks)),
+                              C.c_void_p(out.ctypes.data))
+    return out
+
+
 def fft(data, log_n, inverse=False):
     a = np.ascontiguousarray(data, dtype=np.uint64).copy()
     lib().g16cpu_fft(C.c_void_p(a.ctypes.data), C.c_int(log_n), C.c_int(1 if inverse else 0))

@@ -520,4 +520,18 @@ void g16cpu_g1_mul(const uint8_t P[64], const u64 k[4], uint8_t out[64]) {
   g1_jac j, r; g1_from_aff(&j, (const g1_aff*)P); g1_mul(&r, &j, k);
   g1_aff a; g1_to_aff(&a, &r); memcpy(out, &a, 64);
 }
+void g16cpu_g2_mul(const uint8_t P[128], const u64 k[4], uint8_t out[128]) {
+  g2_jac j, r; g2_from_aff(&j, (const g2_aff*)P); g2_mul(&r, &j, k);
+  g2_aff a; g2_to_aff(&a, &r); memcpy(out, &a, 128);
+}
+/* out[i] = k_i * P for n canonical scalars: how the tests turn the oracle's trapdoor SCALARS into the
+ * key points they compare a key generator's output with (plain MSB-first double-and-add, G##_mul) */
+void g16cpu_g1_mul_batch(const uint8_t P[64], const u64* k, size_t n, uint8_t* out) {
+  _Pragma("omp parallel for schedule(dynamic, 16)")
+  for (size_t i = 0; i < n; ++i) g16cpu_g1_mul(P, k + 4 * i, out + 64 * i);
+}
+void g16cpu_g2_mul_batch(const uint8_t P[128], const u64* k, size_t n, uint8_t* out) {
+  _Pragma("omp parallel for schedule(dynamic, 16)")
+  for (size_t i = 0; i < n; ++i) g16cpu_g2_mul(P, k + 4 * i, out + 128 * i);
+}
 void g16cpu_fft(u64* data, int log_n, int inverse) { fft(data, log_n, inverse); }

@@ -357,6 +357,64 @@ def test_capacity_point_2p25_on_one_gpu(gpulib):
         assert proof.raw == cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
 
 
+@pytest.mark.parametrize("kind,k", [("dense", 12), ("chain", 12), ("chain", 14), ("chain", 16), ("chain", 20)])
+def test_key_generator_pinned_to_the_oracles_trapdoor_scalars(gpulib, kind, k):
+    """Every large test proves under a key minted by the product's own g16_setup_create, and a
+    self-consistent wrong key would still give GPU bytes == CPU bytes.  So the key generator is pinned
+    one level up: the oracle's trapdoor SCALARS (bn254_ref.trapdoor_scalars: Lagrange values at tau,
+    the A / B / C column sums, CircomReduction::h_query_scalars of qap.rs:90-105 -- field operations
+    only) say that every query point is k_i * G; 1000 random indices per query (+ the ends) of the
+    GPU-made A, B1, B2, L and H arrays are compared with k_i * G formed by the C restatement's plain
+    double-and-add (pinned to bn254_ref in tests/test_oracle.py).  At 2^16 / 2^20 the two big inverse
+    transforms of the scalar side run on the C restatement's FFT (pinned likewise)."""
+    import circom_compat_amd as cc
+    import cpu_ref
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    R = o.R_MOD
+    if kind == "dense":
+        mats, (A, B, Cm), w_ints, n_vars = bench.dense_skewed_circuit(cc, k)
+    else:
+        mats, (A, B, Cm), w_ints, n_vars = bench.chain_circuit(cc, k)
+    rng = random.Random(k * 3 + len(kind))
+    tox = [rng.randrange(1, R) for _ in range(5)]
+    pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox)
+
+    def rows(M):
+        co = cc.fr_to_ints(M.coeff)
+        col = M.col.tolist()
+        rp = M.row_ptr.tolist()
+        return [list(zip(col[rp[i]:rp[i + 1]], co[rp[i]:rp[i + 1]])) for i in range(len(rp) - 1)]
+    cons = list(zip(rows(A), rows(B), rows(Cm)))
+
+    def c_ntt(x, inverse=False):
+        lg = (len(x) - 1).bit_length()
+        return cc.fr_to_ints(cpu_ref.fft(cc.fr_from_ints(x), lg, inverse=inverse))
+    td = o.trapdoor_scalars(cons, n_vars, 1, *tox, ntt_fn=c_ntt if k >= 16 else None)
+    assert td["domain_size"] == pk.domain_size == 1 << k
+    g1, g2 = o.g1_to_bytes(o.G1_GEN), o.g2_to_bytes(o.G2_GEN)
+
+    def check(name, arr, scal, mul, base):
+        n = len(scal)
+        assert arr.shape[0] == n, (name, arr.shape, n)
+        idx = sorted(set([0, 1, n - 2, n - 1] + [rng.randrange(n) for _ in range(1000)]))
+        want = mul(base, [scal[i] for i in idx])
+        bad = [i for j, i in enumerate(idx) if bytes(arr[i]) != bytes(want[j])]
+        assert not bad, "%s: %d of %d sampled points differ from k * G, first at index %d" % (name, len(bad), len(idx), bad[0])
+    check("a_query", pk.a_query, td["u"], cpu_ref.g1_mul_batch, g1)
+    check("b_g1_query", pk.b_g1_query, td["v"], cpu_ref.g1_mul_batch, g1)
+    check("b_g2_query", pk.b_g2_query, td["v"], cpu_ref.g2_mul_batch, g2)
+    check("l_query", pk.l_query, td["k_l"], cpu_ref.g1_mul_batch, g1)
+    check("h_query", pk.h_query, td["k_h"], cpu_ref.g1_mul_batch, g1)
+    ic = cpu_ref.g1_mul_batch(g1, td["k_ic"])
+    assert [bytes(x) for x in pk.vk.gamma_abc_g1] == [bytes(x) for x in ic]
+    for name, kk in (("alpha_g1", tox[1]), ("beta_g1", tox[2]), ("delta_g1", tox[4])):
+        got = pk.vk.alpha_g1 if name == "alpha_g1" else getattr(pk, name)
+        assert bytes(got) == bytes(cpu_ref.g1_mul_batch(g1, [kk])[0]), name
+    for name, kk in (("beta_g2", tox[2]), ("gamma_g2", tox[3]), ("delta_g2", tox[4])):
+        assert bytes(getattr(pk.vk, name)) == bytes(cpu_ref.g2_mul_batch(g2, [kk])[0]), name
+
+
 def test_fewer_planes_than_windows_2p22_bytes(gpulib):
     """The fallback every domain above the full-plane capacity point (2^25) runs on -- planes < W, D > 1
     bucket sets per MSM folded by k_horner with c doublings in between -- on the REAL kernels at the

@@ -496,6 +496,39 @@ def test_error_paths_through_the_abi(lib, golden):
     assert len(pr.prove(1, 2, [1, 33, 3, 11]).raw) == 256
 
 
+@pytest.mark.parametrize("corrupt,devices,word", [("0:1:2", [0] * 4, "exchange 0"), ("1:3:0", [0] * 4, "exchange 1"),
+                                                    ("2:1:0", [0] * 4, "gather"), ("2:2:0", [0] * 3, "gather"),
+                                                    ("0:0:0", [0] * 2, "exchange 0")])
+def test_multi_device_create_self_test_catches_a_misrouted_chunk(lib, monkeypatch, corrupt, devices, word):
+    """g16_ctx_create_multi runs a 4 KiB-per-pair all-to-all echo and a gather of the partial records
+    through the very code a proof's exchanges use (csrc/multi.hip: push_chunks / await_chunks behind
+    ev_send on the aux stream, the peer copies behind ev_part), with known patterns.  With one copy
+    deliberately reading the wrong source (G16_DEBUG_SELFTEST_CORRUPT = exchange:src:dst, a test-only
+    hook) creation must FAIL and name the pair -- a broken peer path between two devices is an error
+    at create, never a wrong proof; without the hook the same ctx is created and proves (the test
+    above).  Three ranks: no distributed witness map, so only the gather exists and is checked."""
+    import circom_compat_amd as cc
+    cons, w, n_vars, n_pub = H.squaring_chain(4)
+    rng = random.Random(4)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    opk = o.trapdoor_setup(cons, n_vars, n_pub, *tox)
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, lib)
+    pk = H.pk_from_oracle(opk)
+    x, src, dst = (int(t) for t in corrupt.split(":"))
+    monkeypatch.setenv("G16_DEBUG_SELFTEST_CORRUPT", corrupt)
+    with pytest.raises(cc.G16Error) as e:
+        cc.Prover(pk, mats, lib=lib, devices=devices)
+    msg = str(e.value)
+    assert "self-test failed" in msg and word in msg and "rank %d " % src in msg and "-> rank %d " % dst in msg, msg
+    monkeypatch.delenv("G16_DEBUG_SELFTEST_CORRUPT")
+    pr = cc.Prover(pk, mats, lib=lib, devices=devices)      # and the healthy path is created and proves
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2, len(cons), w)
+    assert pr.prove(r, s, w).raw == o.proof_to_bytes(want)
+    pr.close()
+
+
 @pytest.mark.parametrize("shard", ["points", "buckets"])
 @pytest.mark.parametrize("logm,devices", [(4, [0, 0]), (5, [0, 0, 0, 0]), (4, [0, 0, 0])])
 def test_in_library_multi_device_prover(lib, logm, devices, shard):

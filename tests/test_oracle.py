@@ -245,3 +245,70 @@ def test_c_oracle_libsnark_reduction_matches_python_oracle(logm, kind):
     assert got == o.proof_to_bytes(want)
     if logm <= 8:
         assert o.verify_proof(opk, wit[1:ni], want)
+
+
+def test_c_oracle_scalar_mul_matches_python_oracle():
+    """g16cpu_g1_mul_batch / g16cpu_g2_mul_batch (k * P by plain double-and-add) == bn254_ref's G1.mul /
+    G2.mul: the helper the GPU suite uses to turn the oracle's trapdoor SCALARS (trapdoor_scalars, no
+    group operations) into the points a key generator's output is compared with at 2^12 .. 2^20."""
+    import cpu_ref
+    rng = random.Random(12)
+    ks = [0, 1, 2, o.R_MOD - 1] + [rng.randrange(o.R_MOD) for _ in range(28)]
+    g1 = cpu_ref.g1_mul_batch(o.g1_to_bytes(o.G1_GEN), ks)
+    g2 = cpu_ref.g2_mul_batch(o.g2_to_bytes(o.G2_GEN), ks)
+    for i, k in enumerate(ks):
+        assert bytes(g1[i]) == o.g1_to_bytes(o.G1.mul(o.G1_GEN, k)), k
+        assert bytes(g2[i]) == o.g2_to_bytes(o.G2.mul(o.G2_GEN, k)), k
+    p = o.G1.mul(o.G1_GEN, 77)
+    got = cpu_ref.g1_mul_batch(o.g1_to_bytes(p), ks[:8])
+    assert [bytes(x) for x in got] == [o.g1_to_bytes(o.G1.mul(p, k)) for k in ks[:8]]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("logm", [12, 14])
+def test_c_oracle_prove_matches_python_oracle_2p12_2p14(logm):
+    """oracle/groth16_cpu.c's CircomReduction prove == oracle/bn254_ref.py at 2^12 and 2^14 constraints
+    with uneven rows (dense-skewed family + one 9-term row): h element for element and the 256 proof
+    bytes.  This moves the byte-level pin of the C restatement -- the checker of every GPU proof at
+    2^14 .. 2^26 -- from 2^10 to 2^14 (MSM windows c = 10 / 11, 14-stage FFTs).  The key cycles through 64 random points
+    (prove is linear in the key: no trapdoor structure is needed, and 4096 x 6 Python scalar
+    multiplications would take minutes)."""
+    import cpu_ref
+    cons, wit, nv, _ = H.dense_skewed_circuit((1 << logm) - 5, seed=12, long_rows=(9,))
+    npub, ni = 1, 2
+    rng = random.Random(logm)
+    K = 64
+    b1 = [o.G1.mul(o.G1_GEN, rng.randrange(1, o.R_MOD)) for _ in range(K)]
+    b2 = [o.G2.mul(o.G2_GEN, rng.randrange(1, o.R_MOD)) for _ in range(K)]
+    n = o.domain_size_for(len(cons) + ni)
+    assert n == 1 << logm
+    opk = dict(n_vars=nv, n_public=npub, domain_size=n, alpha_g1=b1[0], beta_g1=b1[1], beta_g2=b2[0], gamma_g2=b2[1],
+               delta_g1=b1[2], delta_g2=b2[2], ic=b1[:2],
+               a_query=[b1[i % K] for i in range(nv)], b_g1_query=[b1[(i * 7 + 1) % K] for i in range(nv)],
+               b_g2_query=[b2[(i * 5 + 2) % K] if i % 13 else None for i in range(nv)],
+               l_query=[b1[(i * 3 + 5) % K] for i in range(nv - ni)], h_query=[b1[(i * 11 + 3) % K] for i in range(n)])
+    ar, br = o.matrices_from_r1cs(cons)
+
+    class M:
+        pass
+
+    def csr(rows):
+        m = M()
+        m.row_ptr = np.array([0] + list(np.cumsum([len(r) for r in rows])), dtype=np.uint32)
+        m.col = np.array([i for r in rows for _c, i in r], dtype=np.uint32)
+        m.coeff = H.fr_mont_arr([c for r in rows for c, _i in r])
+        return m
+    mats = M()
+    mats.a, mats.b, mats.num_constraints = csr(ar), csr(br), len(cons)
+    pk = M()
+    pk.n_vars, pk.n_public, pk.domain_size = nv, npub, n
+    pk.a_query, pk.b_g1_query, pk.b_g2_query = H.g1_arr(opk["a_query"]), H.g1_arr(opk["b_g1_query"]), H.g2_arr(opk["b_g2_query"])
+    pk.l_query, pk.h_query = H.g1_arr(opk["l_query"]), H.g1_arr(opk["h_query"])
+    pk.vk = M()
+    pk.vk.alpha_g1, pk.vk.beta_g2, pk.vk.delta_g2 = o.g1_to_bytes(opk["alpha_g1"]), o.g2_to_bytes(opk["beta_g2"]), o.g2_to_bytes(opk["delta_g2"])
+    pk.beta_g1, pk.delta_g1 = o.g1_to_bytes(opk["beta_g1"]), o.g1_to_bytes(opk["delta_g1"])
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    got, h = cpu_ref.prove(pk, mats, H.fr_mont_arr([r]), H.fr_mont_arr([s]), H.fr_mont_arr(wit), want_h=True)
+    assert H.fr_from_mont_arr(h) == o.witness_map_from_matrices(ar, br, ni, len(cons), wit)
+    want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=ar, b=br), ni, len(cons), wit)
+    assert got == o.proof_to_bytes(want)
