@@ -116,11 +116,12 @@ void accumulate_ab(g16_ctx* c, hipStream_t s, StageTimer* tm, bool fixup = true)
 }
 // the deferred exact additions of accumulate_ab(fixup = false), on the stream that reduces A and B1
 void fixup_ab(g16_ctx* c, hipStream_t q) {
+  StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   if (c->ptsA.stride == 2) {
-    msm_fixup_pair<Fq>(c->sort_w, c->ptsA, c->ptsB1, c->work1, 0, q);
+    msm_fixup_pair<Fq>(c->sort_w, c->ptsA, c->ptsB1, c->work1, 0, q, tm);
   } else {
-    msm_fixup<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, q);
-    msm_fixup<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, q);
+    msm_fixup<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, q, tm);
+    msm_fixup<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, q, tm);
   }
 }
 
@@ -189,7 +190,7 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm, /*fixup=*/fix_inline);
     G16_HIP(hipEventRecord(c->ev_acc[2], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[2], 0));
-    if (!fix_inline) msm_fixup<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, q);
+    if (!fix_inline) msm_fixup<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, q, tm);
     msm_reduce<Fq>(c->sort_w, c->work1, 2, 1, &S->L, q, tm, /*hidden=*/true);
     after_b2();
     G16_HIP(hipEventRecord(c->ev_b2, q));
@@ -548,6 +549,8 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     c->p = key->n_public;
     c->num_inputs = c->p + 1;
     c->m = num_constraints;
+    c->nnz_a = a->nnz;
+    c->nnz_b = b->nnz;
     CsrHost A{a->row_ptr, a->col, (const Fr*)a->coeff, (size_t)a->nnz};
     CsrHost B{b->row_ptr, b->col, (const Fr*)b->coeff, (size_t)b->nnz};
     if (o.reduction != G16_REDUCTION_CIRCOM && o.reduction != G16_REDUCTION_LIBSNARK)
@@ -574,10 +577,11 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     // 21.4 ms at 2^24 -- because a bucket-sharded rank walks ALL n scalars to keep an eighth of the
     // digits and that front costs what the single-GPU window saves; point ranges need 1/world of the
     // key per device instead of all of it.  DESIGN.md section 7.
-    c->shard_buckets = (c->world > 1 || c->dist_wm) && c->has_key && o.shard == G16_SHARD_BUCKETS;
+    c->shard_buckets = c->world > 1 && c->has_key && o.shard == G16_SHARD_BUCKETS;  // one rank: nothing to cut
     if (c->shard_buckets && !share_from && !bucket_shard_fits(c->device, c->N, c->n, &o))
       throw std::runtime_error("G16_SHARD_BUCKETS: the full point planes of the witness queries do not fit this device");
     c->share_from = (c->shard_buckets || c->world == 1) ? share_from : nullptr;
+    if (c->share_from) ++c->share_from->borrowers;
     // the H query is ALWAYS cut by point range: its scalars are born sharded (the distributed
     // witness map leaves rank g the n / world evaluations e = global_index(t)), so every rank
     // multiplies its own slice; only the witness-scalar queries (A, B1, B2, L: the witness is
@@ -733,8 +737,16 @@ g16_status g16_ctx_create_sibling(g16_ctx* donor, const g16_key_desc* key, const
   o.rank = 0;
   o.world = 1;
   o.dist_wm = 0;
+  if (donor->multi || donor->share_from || !donor->has_key)
+    return fail(nullptr, G16_ERR_INVALID, "sibling: the donor must be a plain single-device proving ctx that owns its planes");
   if (key && (key->n_vars != donor->N || key->n_public != donor->p || key->domain_size != donor->n))
     return fail(nullptr, G16_ERR_INVALID, "sibling: not the donor's key");
+  // the planes (and with them the window and plane count) are the donor's: a conflicting request is an
+  // error, not something to ignore; so is a matrix pair of another shape (same sizes, other circuit)
+  if ((o.window_bits > 0 && o.window_bits != donor->cfg_w.c) || (o.planes > 0 && o.planes != donor->cfg_w.Pn))
+    return fail(nullptr, G16_ERR_INVALID, "sibling: window_bits / planes differ from the donor's configuration");
+  if (num_constraints != donor->m || !a || !b || a->nnz != donor->nnz_a || b->nnz != donor->nnz_b)
+    return fail(nullptr, G16_ERR_INVALID, "sibling: not the donor's constraint matrices");
   std::string err;
   const g16_status st = ctx_create_impl(key, a, b, num_constraints, &o, donor, out, &err);
   if (st != G16_OK) return fail(nullptr, st, err);
@@ -743,6 +755,9 @@ g16_status g16_ctx_create_sibling(g16_ctx* donor, const g16_key_desc* key, const
 
 void g16_ctx_destroy(g16_ctx* c) {
   if (!c) return;
+  if (c->borrowers > 0)  // documented contract: the donor outlives its siblings; say so instead of corrupting them
+    fprintf(stderr, "libg16_amd: g16_ctx_destroy on a ctx that still lends its point planes to %d ctx(s)\n", c->borrowers);
+  if (c->share_from) --c->share_from->borrowers;
   if (c->multi) {  // parent of a multi-device prover: the children own all device state
     multi_destroy(c->multi);
     if (c->pinned_w) (void)hipHostFree(c->pinned_w);
@@ -1103,7 +1118,7 @@ g16_status g16_stage_times(g16_ctx* c, float ms[G16_N_STAGES], uint32_t launches
 const char* g16_stage_name(int stage) {
   static const char* names[ST_COUNT] = {"witness_map",       "msm_sort",   "msm_accumulate_g1",
                                         "msm_accumulate_g2", "msm_reduce", "finalize",
-                                        "msm_accumulate_g1_pair"};
+                                        "msm_accumulate_g1_pair", "msm_fixup"};
   return (stage >= 0 && stage < ST_COUNT) ? names[stage] : "?";
 }
 

@@ -81,6 +81,7 @@ enum Stage {
   ST_MSM_REDUCE,
   ST_FINALIZE,
   ST_MSM_ACC_G1_PAIR,  // k_bucket_accumulate<Fq, 2, true>: A and B1 in one launch (interleaved pair)
+  ST_MSM_FIXUP,        // k_acc_fixup + the exact kernel behind an optimistic G1 launch (early exit unless the list overflowed)
   ST_COUNT
 };
 

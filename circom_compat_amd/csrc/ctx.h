@@ -85,6 +85,8 @@ struct g16_ctx {
   // of its own, only the per-device children and the exchange plumbing between them
   g16::Multi* multi = nullptr;
   g16_ctx* share_from = nullptr;  // lender of the point planes (must outlive this ctx)
+  int borrowers = 0;              // live ctxs that borrow this one's planes
+  uint64_t nnz_a = 0, nnz_b = 0;  // shape of the constraint matrices (g16_ctx_create_sibling checks them)
   uint32_t peer_state = 0;        // multi-device parent: 1 = every peer pair has direct access, 2 = some copies are staged
 
   uint8_t* part_dev() { return out_dev.p + G16_PROOF_BYTES; }

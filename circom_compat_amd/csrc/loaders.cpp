@@ -194,7 +194,9 @@ struct FileView {
         return true;
       }
     }
-    (void)madvise(m, n, MADV_WILLNEED);
+    // sequential access hint only: MADV_WILLNEED on a multi-10-GB zkey would start a whole-file
+    // readahead up front, while the sections are uploaded one after another
+    (void)madvise(m, n, MADV_SEQUENTIAL);
     map = m;
     p = (const uint8_t*)m;
     return true;

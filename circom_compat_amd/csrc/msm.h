@@ -236,7 +236,7 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min,
 // slots `slot` and `slot + 1`): k_acc_fixup + the exact kernel that redoes an overflowed launch
 template <class F>
 void msm_fixup(const MsmSort& s, const MsmPoints<F>& pts, uint32_t idx_min, MsmWork<F>& work, int slot,
-               hipStream_t stream);
+               hipStream_t stream, StageTimer* tm = nullptr);
 // a, b: the two halves of an interleaved pair (MsmPoints::init_pair).  ONE launch: the two waves of
 // a workgroup walk the same 64 segments, wave 0 adding a's points into `slot`, wave 1 b's points into
 // `slot + 1` -- the second wave finds the 128-byte line its neighbour just pulled in the cache.
@@ -246,7 +246,7 @@ void msm_accumulate_pair(const MsmSort& s, const MsmPoints<F>& a, const MsmPoint
                          bool fixup = true);
 template <class F>
 void msm_fixup_pair(const MsmSort& s, const MsmPoints<F>& a, const MsmPoints<F>& b, MsmWork<F>& work,
-                    int slot, hipStream_t stream);
+                    int slot, hipStream_t stream, StageTimer* tm = nullptr);
 template <class F>
 void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, MsmAcc<F>* out_dev,
                 hipStream_t stream, StageTimer* tm = nullptr, bool hidden = false);

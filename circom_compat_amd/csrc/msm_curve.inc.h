@@ -583,7 +583,7 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
       G16_LAUNCH((k_bucket_accumulate<F, 1, false, true>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
                  idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, fix);
     if (tm) tm->end(id, stream);
-    if (fixup) msm_fixup<F>(s, P, idx_min, work, slot, stream);
+    if (fixup) msm_fixup<F>(s, P, idx_min, work, slot, stream, tm);
     return;
   }
   if (P.stride == 2)
@@ -597,8 +597,9 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
 
 template <class F>
 void msm_fixup(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<F>& work, int slot,
-               hipStream_t stream) {
+               hipStream_t stream, StageTimer* tm) {
   if (!(sizeof(F) == sizeof(Fq) ? acc_fast() : acc_fast_g2())) return;
+  const int tid = tm ? tm->begin(ST_MSM_FIXUP, stream) : -1;
   const MsmConfig& cfg = s.cfg;
   const uint32_t nb = cfg.nb();
   const uint32_t lanes = s.lanes_of(sizeof(F) != sizeof(Fq));
@@ -624,6 +625,7 @@ void msm_fixup(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWor
     G16_LAUNCH((k_bucket_accumulate<F, 1, false, false>), grid_x, ACC_THREADS, 0, stream, P.data(), P.count,
                idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, fix);
   }
+  if (tm) tm->end(tid, stream);
 }
 
 template <class F>
@@ -647,7 +649,7 @@ void msm_accumulate_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoint
       G16_LAUNCH((k_bucket_accumulate<F, 2, true, true>), grid, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
                  cfg.idx_bits, en, of, nb, cfg.lanes, out, (size_t)work.slots, work.fix.p + slot);
       if (tm) tm->end(id, stream);
-      if (fixup) msm_fixup_pair<F>(s, A, B, work, slot, stream);
+      if (fixup) msm_fixup_pair<F>(s, A, B, work, slot, stream, tm);
       return;
     }
   }
@@ -658,10 +660,11 @@ void msm_accumulate_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoint
 
 template <class F>
 void msm_fixup_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoints<F>& B, MsmWork<F>& work,
-                    int slot, hipStream_t stream) {
+                    int slot, hipStream_t stream, StageTimer* tm) {
   (void)B;
   if constexpr (sizeof(F) == sizeof(Fq)) {
     if (!acc_fast()) return;
+    const int tid = tm ? tm->begin(ST_MSM_FIXUP, stream) : -1;
     const MsmConfig& cfg = s.cfg;
     const uint32_t nb = cfg.nb();
     const uint32_t grid = cfg.lanes / (ACC_THREADS / 2);
@@ -672,6 +675,7 @@ void msm_fixup_pair(const MsmSort& s, const MsmPoints<F>& A, const MsmPoints<F>&
     G16_LAUNCH((k_bucket_accumulate<F, 2, true, false>), grid_x, ACC_THREADS, 0, stream, A.data(), A.count, 0u,
                cfg.idx_bits, (const uint32_t*)s.entries.p, (const uint32_t*)s.offset.p, nb, cfg.lanes, out,
                (size_t)work.slots, fix);
+    if (tm) tm->end(tid, stream);
   }
 }
 

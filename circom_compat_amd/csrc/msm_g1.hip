@@ -7,11 +7,11 @@ template void msm_run<Fq>(const MsmSort&, const MsmPoints<Fq>&, uint32_t, MsmWor
                           hipStream_t, StageTimer*);
 template void msm_accumulate<Fq>(const MsmSort&, const MsmPoints<Fq>&, uint32_t, MsmWork<Fq>&, int,
                                  hipStream_t, StageTimer*, bool);
-template void msm_fixup<Fq>(const MsmSort&, const MsmPoints<Fq>&, uint32_t, MsmWork<Fq>&, int, hipStream_t);
+template void msm_fixup<Fq>(const MsmSort&, const MsmPoints<Fq>&, uint32_t, MsmWork<Fq>&, int, hipStream_t, StageTimer*);
 template void msm_accumulate_pair<Fq>(const MsmSort&, const MsmPoints<Fq>&, const MsmPoints<Fq>&,
                                       MsmWork<Fq>&, int, hipStream_t, StageTimer*, bool);
 template void msm_fixup_pair<Fq>(const MsmSort&, const MsmPoints<Fq>&, const MsmPoints<Fq>&, MsmWork<Fq>&, int,
-                                 hipStream_t);
+                                 hipStream_t, StageTimer*);
 template void msm_reduce<Fq>(const MsmSort&, MsmWork<Fq>&, int, int, MsmAcc<Fq>*, hipStream_t,
                              StageTimer*, bool);
 }  // namespace g16

@@ -7,7 +7,7 @@ template void msm_run<Fq2>(const MsmSort&, const MsmPoints<Fq2>&, uint32_t, MsmW
                            MsmAcc<Fq2>*, hipStream_t, StageTimer*);
 template void msm_accumulate<Fq2>(const MsmSort&, const MsmPoints<Fq2>&, uint32_t, MsmWork<Fq2>&, int,
                                  hipStream_t, StageTimer*, bool);
-template void msm_fixup<Fq2>(const MsmSort&, const MsmPoints<Fq2>&, uint32_t, MsmWork<Fq2>&, int, hipStream_t);
+template void msm_fixup<Fq2>(const MsmSort&, const MsmPoints<Fq2>&, uint32_t, MsmWork<Fq2>&, int, hipStream_t, StageTimer*);
 template void msm_reduce<Fq2>(const MsmSort&, MsmWork<Fq2>&, int, int, MsmAcc<Fq2>*, hipStream_t,
                              StageTimer*, bool);
 }  // namespace g16

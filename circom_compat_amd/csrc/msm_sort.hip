@@ -141,8 +141,9 @@ __device__ __forceinline__ void for_each_digit(const U256& scalar, uint32_t i, i
 // ---- two-level counting sort of the (bucket, entry) pairs ---------------------------------------
 // A single-level sort needs one global atomic per entry and per pass (2 x 58.7 M at n = 2^22:
 // 8.7 ms).  Here every pass aggregates in LDS first:
-//   level 1: partition by the top bits of the bucket id (<= 1024 partitions); per tile of 2048
-//            scalars one LDS histogram, one global atomic per (tile, partition);
+//   level 1: partition by the top bits of the bucket id (<= 1024 partitions); no global atomics: pass
+//            A leaves per-block partition histograms, their exclusive scan in [partition][block]
+//            order IS every block's write position, pass B ranks its digits with LDS cursors;
 //   level 2: inside a partition-ordered array a chunk of 16 K entries spans a contiguous range of
 //            <= 4096 buckets: LDS histogram / LDS ranks again, one global atomic per (chunk, bucket).
 // Order inside a bucket is arbitrary (EC addition commutes), which is what makes atomics-based

@@ -71,7 +71,10 @@ typedef struct {
   int rank, world; /* point-range shard of the MSMs owned by this ctx (world = 1: everything)   */
   int window_bits; /* MSM window c; <= 0: automatic                                              */
   int planes;      /* stored multiples 2^(c*D*j)P per point; <= 0: as many as fit (full = W)     */
-  int dist_wm;     /* world > 1 only: distribute the witness map too (g16_prove_dist_phase*)      */
+  int dist_wm;     /* > 0: distribute the witness map too; the ctx then proves ONLY through the
+                      g16_prove_dist_phase* calls (g16_prove answers G16_ERR_INVALID).  world = 1 with
+                      dist_wm = 1 is the degenerate one-rank case of that API (every exchange copies onto
+                      itself: what a one-process run of the host framework's collectives drives)      */
   int reduction;   /* G16_REDUCTION_CIRCOM (0, default) or G16_REDUCTION_LIBSNARK                  */
   int shard;       /* world > 1: G16_SHARD_AUTO (0), G16_SHARD_POINTS, G16_SHARD_BUCKETS (below)    */
 } g16_options;
@@ -220,7 +223,7 @@ g16_status g16_prove_dist_phase3(g16_ctx* ctx, const void* recv_dev,
                                  uint8_t partial_out[G16_PARTIAL_BYTES]);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
-#define G16_N_STAGES 7
+#define G16_N_STAGES 8
 g16_status g16_set_profiling(g16_ctx* ctx, int enabled);
 /* HIP-event times accumulated since the last call; resets the accumulators.                       */
 g16_status g16_stage_times(g16_ctx* ctx, float ms[G16_N_STAGES], uint32_t launches[G16_N_STAGES]);

@@ -15,7 +15,7 @@ pub const G16_ERR_INTERNAL: g16_status = 6;
 
 pub const G16_PROOF_BYTES: usize = 256;
 pub const G16_PARTIAL_BYTES: usize = 1024;
-pub const G16_N_STAGES: usize = 7;
+pub const G16_N_STAGES: usize = 8;
 pub const G16_SHARD_AUTO: c_int = 0;
 pub const G16_SHARD_POINTS: c_int = 1;
 pub const G16_SHARD_BUCKETS: c_int = 2;

@@ -2,13 +2,18 @@
 //! reference src/circom/qap.rs:14-106) whose `witness_map_from_matrices` runs on the GPU.
 //!
 //! The trait is stateless (static methods, no `self`), so the resident state lives in a
-//! thread-local cache keyed by the matrices' CONTENT (shape + a 64-bit FNV-1a hash over every row's
-//! coefficients and indices; an address would be reused by a freed-and-reallocated `Vec` of the
-//! same shape and silently pair a stale device ctx with new matrices): the first call uploads A
-//! and B, later calls with equal matrices only upload the witness.  Hashing is one pass over nnz
-//! (coefficient, index) pairs -- cheaper than the pack + upload it saves.  The MSMs inside
-//! `ark_groth16` are not overridable through this trait -- use `GpuProver` / `Groth16Gpu` for the
-//! whole proof; this impl exists for callers that only want `h`.
+//! thread-local cache.  Identifying "the same matrices" has to be both cheap and safe:
+//!   * fast path (every call): the addresses and lengths of the outer `Vec`s and of their first rows
+//!     match the cached ones AND a fixed sample of 64 rows compares equal element for element --
+//!     O(1), no hashing.  (An address alone would be reused by a freed-and-reallocated `Vec` of the
+//!     same shape and silently pair a stale device ctx with new matrices; the row sample catches that
+//!     for anything but an adversarially similar matrix, and the slow path below settles it.)
+//!   * slow path (addresses or shape changed): a 128-bit content hash over every row's indices and
+//!     the coefficients' raw Montgomery limbs, eight bytes per step (no `into_bigint()`: one Montgomery
+//!     reduction per coefficient cost more than the GPU witness map it guards) -- equal hash: the ctx is
+//!     kept and re-bound to the new addresses; different: A and B are packed and uploaded again.
+//! The MSMs inside `ark_groth16` are not overridable through this trait -- use `GpuProver` /
+//! `Groth16Gpu` for the whole proof; this impl exists for callers that only want `h`.
 use std::any::TypeId;
 use std::cell::RefCell;
 
@@ -24,8 +29,54 @@ use crate::pack::{self, Csr};
 
 pub struct GpuCircomReduction;
 
+/// where the matrices live: outer Vec addresses / lengths and the first rows' addresses
+#[derive(Clone, Copy, PartialEq, Eq)]
+struct Ident {
+    a_ptr: usize,
+    a_len: usize,
+    b_ptr: usize,
+    b_len: usize,
+    a_row0: usize,
+    b_row0: usize,
+}
+fn ident_of(m: &ConstraintMatrices<Fr>) -> Ident {
+    Ident {
+        a_ptr: m.a.as_ptr() as usize,
+        a_len: m.a.len(),
+        b_ptr: m.b.as_ptr() as usize,
+        b_len: m.b.len(),
+        a_row0: m.a.first().map_or(0, |r| r.as_ptr() as usize),
+        b_row0: m.b.first().map_or(0, |r| r.as_ptr() as usize),
+    }
+}
+
+const SAMPLE_ROWS: usize = 32; // per matrix
+
+/// copies of SAMPLE_ROWS evenly spaced rows of A and of B: (is_b, row index, row)
+type RowSample = Vec<(bool, usize, Vec<(Fr, usize)>)>;
+fn sample_of(m: &ConstraintMatrices<Fr>) -> RowSample {
+    let mut out = Vec::new();
+    for (is_b, mat) in [(false, &m.a), (true, &m.b)] {
+        let n = mat.len();
+        let take = SAMPLE_ROWS.min(n);
+        for j in 0..take {
+            let i = j * n / take;
+            out.push((is_b, i, mat[i].clone()));
+        }
+    }
+    out
+}
+fn sample_matches(m: &ConstraintMatrices<Fr>, s: &RowSample) -> bool {
+    s.iter().all(|(is_b, i, row)| {
+        let mat = if *is_b { &m.b } else { &m.a };
+        mat.get(*i).map_or(false, |r| r == row)
+    })
+}
+
 struct WmCtx {
-    key: (u64, usize, usize, usize), // (content hash of A and B, num_constraints, num_inputs, n_vars)
+    key: ((u64, u64), usize, usize, usize), // (content hash of A and B, num_constraints, num_inputs, n_vars)
+    ident: Ident,
+    sample: RowSample,
     ctx: *mut ffi::g16_ctx,
     domain_size: usize,
 }
@@ -38,14 +89,13 @@ thread_local! {
     static CACHE: RefCell<Option<WmCtx>> = RefCell::new(None);
 }
 
-/// FNV-1a over the rows of A and B: row lengths, wire indices and the coefficients' limbs
-fn content_hash(m: &ConstraintMatrices<Fr>) -> u64 {
-    let mut h: u64 = 0xcbf29ce484222325;
+/// 128-bit content hash (two independent multiply-rotate lanes over 64-bit words) of the rows of A
+/// and B: row lengths, wire indices and the coefficients' raw Montgomery limbs
+fn content_hash(m: &ConstraintMatrices<Fr>) -> (u64, u64) {
+    let (mut h1, mut h2): (u64, u64) = (0x9e37_79b9_7f4a_7c15, 0xc2b2_ae3d_27d4_eb4f);
     let mut eat = |x: u64| {
-        for b in x.to_le_bytes() {
-            h ^= b as u64;
-            h = h.wrapping_mul(0x100000001b3);
-        }
+        h1 = (h1 ^ x).wrapping_mul(0xff51_afd7_ed55_8ccd).rotate_left(27);
+        h2 = (h2.rotate_left(31) ^ x.wrapping_mul(0x9fb2_1c65_1e98_df25)).wrapping_mul(0xc4ce_b9fe_1a85_ec53);
     };
     for mat in [&m.a, &m.b] {
         eat(mat.len() as u64);
@@ -53,13 +103,20 @@ fn content_hash(m: &ConstraintMatrices<Fr>) -> u64 {
             eat(row.len() as u64);
             for (coeff, idx) in row.iter() {
                 eat(*idx as u64);
-                for limb in coeff.into_bigint().0 {
-                    eat(limb);
+                for limb in (coeff.0).0 {
+                    eat(limb); // Montgomery limbs as stored: equal elements have equal limbs
                 }
             }
         }
     }
-    h
+    // final avalanche of both lanes
+    let fin = |mut z: u64| {
+        z ^= z >> 33;
+        z = z.wrapping_mul(0xff51_afd7_ed55_8ccd);
+        z ^= z >> 29;
+        z
+    };
+    (fin(h1), fin(h2 ^ h1.rotate_left(17)))
 }
 
 fn gpu_witness_map(
@@ -68,10 +125,26 @@ fn gpu_witness_map(
     num_constraints: usize,
     full_assignment: &[Fr],
 ) -> Result<Vec<Fr>, SynthesisError> {
-    let key = (content_hash(matrices), num_constraints, num_inputs, full_assignment.len());
+    let ident = ident_of(matrices);
+    let shape = (num_constraints, num_inputs, full_assignment.len());
     CACHE.with(|cell| {
         let mut slot = cell.borrow_mut();
-        if slot.as_ref().map(|c| c.key) != Some(key) {
+        // fast path: same place, same shape, and the row sample still reads the same
+        let hit = slot.as_ref().map_or(false, |c| {
+            c.ident == ident && (c.key.1, c.key.2, c.key.3) == shape && sample_matches(matrices, &c.sample)
+        });
+        let mut key = ((0u64, 0u64), shape.0, shape.1, shape.2);
+        if !hit {
+            key.0 = content_hash(matrices);
+            if let Some(c) = slot.as_mut() {
+                if c.key == key {
+                    // the same matrices at another address: keep the device ctx, re-bind the fast path
+                    c.ident = ident;
+                    c.sample = sample_of(matrices);
+                }
+            }
+        }
+        if !hit && slot.as_ref().map(|c| c.key) != Some(key) {
             *slot = None;
             let domain_size = (num_constraints + num_inputs).next_power_of_two();
             let (ca, cb): (Csr, Csr) = pack::matrices_to_csr(matrices);
@@ -99,7 +172,7 @@ fn gpu_witness_map(
                 ffi::G16_ERR_DOMAIN_TOO_LARGE => return Err(SynthesisError::PolynomialDegreeTooLarge),
                 _ => return Err(SynthesisError::Unsatisfiable),
             }
-            *slot = Some(WmCtx { key, ctx, domain_size });
+            *slot = Some(WmCtx { key, ident, sample: sample_of(matrices), ctx, domain_size });
         }
         let c = slot.as_ref().unwrap();
         let w = pack::fr_vec_words(full_assignment);

@@ -202,6 +202,41 @@ def test_msm_hot_bucket_split(lib):
     assert pr.msm_g1(0, scal) == o.g1_to_bytes(want)
 
 
+def test_optimistic_accumulation_overflow_falls_back_to_the_exact_kernel(lib):
+    """A key whose query points are ALL the same point and a witness of ones: every mixed addition after a
+    lane's first is acc + P with acc = P, i.e. the x-coordinates coincide, the optimistic G1 kernel sets
+    every one of them aside and its 512-entry list overflows (100 segments x 7 deferrals) -- k_acc_fixup
+    raises `overflow` and the exact kernel behind it redoes the launch.  Deterministic, unlike a hot
+    bucket of several points; covers the interleaved A|B1 pair launch (prove) and the single-query
+    launches (L, H, msm_g1).  The G2 launch runs the exact kernel anyway.  Bytes == oracle."""
+    import circom_compat_amd as cc
+    rng = random.Random(812)
+    n = 800
+    N = n + 1
+    P = o.G1.mul(o.G1_GEN, 12345)
+    Q = o.G2.mul(o.G2_GEN, 54321)
+    base = H.rand_g1(rng, 3)
+    g2 = H.rand_g2(rng, 3)
+    pk = dict(n_vars=N, n_public=1, domain_size=4, alpha_g1=base[0], beta_g1=base[1], beta_g2=g2[0], gamma_g2=g2[1],
+              delta_g1=base[2], delta_g2=g2[2], ic=base[:2], a_query=[P] * N, b_g1_query=[P] * N,
+              b_g2_query=[Q] * N, l_query=[P] * (N - 2), h_query=[P] * 4)
+    a_rows, b_rows = [[(1, 1)]], [[(1, 0)]]
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, N, lib)
+    pr = cc.Prover(H.pk_from_oracle(pk), mats, lib=lib, window_bits=16)
+    ones = [1] * n
+    assert pr.msm_g1(0, ones) == o.g1_to_bytes(o.G1.mul(P, n))
+    assert pr.msm_g1(2, ones[:n - 1]) == o.g1_to_bytes(o.G1.mul(P, n - 1))
+    assert pr.msm_g2(ones) == o.g2_to_bytes(o.G2.mul(Q, n))
+    w = [1] * N
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    want = o.create_proof_with_reduction_and_matrices(pk, r, s, dict(a=a_rows, b=b_rows), 2, 1, w)
+    assert pr.prove(r, s, w).raw == o.proof_to_bytes(want)
+    # a mixed case right behind it on the same ctx: the list and its overflow flag are reset per launch
+    w2 = [1] + H.rand_fr(rng, n)
+    want2 = o.create_proof_with_reduction_and_matrices(pk, r, s, dict(a=a_rows, b=b_rows), 2, 1, w2)
+    assert pr.prove(r, s, w2).raw == o.proof_to_bytes(want2)
+
+
 def test_prove_synthetic_circuit_vs_oracle(lib):
     """squaring-chain circuit with a trapdoor key: proof bytes == oracle, proof verifies,
     wrong public input is rejected; also the world = 2 partial/finish path gives the same bytes"""
@@ -797,6 +832,17 @@ def test_sibling_ctx_shares_planes_two_proofs_in_flight(lib, golden):
         for t in ths:
             t.join()
         assert got == want
+    # what a sibling may not do: ask for another window / plane count than the donor's,
+    # borrow from a borrower, bring other matrices of the same sizes
+    with pytest.raises(cc.G16Error):
+        cc.Prover(pk, mats, lib=lib, sibling_of=donor, window_bits=donor.info()["c_w"] + 1)
+    with pytest.raises(cc.G16Error):
+        cc.Prover(pk, mats, lib=lib, sibling_of=donor, planes=1)
+    with pytest.raises(cc.G16Error):
+        cc.Prover(pk, mats, lib=lib, sibling_of=sib)
+    other = H.matrices_from_rows(a_rows[:-1] + [a_rows[-1] + a_rows[-1]], b_rows, 2, n_vars, lib)
+    with pytest.raises(cc.G16Error):
+        cc.Prover(pk, other, lib=lib, sibling_of=donor)
     sib.close()
     assert donor.prove(*rs[0], w).raw == want[0]
     multi = cc.Prover(pk, mats, lib=lib, devices=[0, 0])
