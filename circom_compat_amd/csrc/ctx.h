@@ -45,7 +45,6 @@ struct g16_ctx {
   bool fixed_ready = false;
   // phase 1 sorted the witness scalars only: phase 2 enqueues the witness MSMs (api.hip, rank_phase1_enqueue)
   bool msm_deferred = false;
-  int l_red_deferred = 0;  // the L reduction of the proof being enqueued is still to be launched (api.hip)
   const g16::Fr* w_cur = nullptr;
   uint64_t fixed_rs[8] = {0};
   // Sharding of the MSMs over the ranks (options.shard):

@@ -6,7 +6,10 @@ MSMs, the partial record and the finish -- except that the exchanges are replace
 of the same byte counts on the exchange stream.  xGMI time is therefore NOT in T_rank; the bytes a
 rank sends per proof and the link time they take at a stated per-link rate are printed beside it.
 
-    python scripts/dist_projection.py [log2=22] [worlds=2,4,8] [reps=5] [modes=points,buckets]
+    python scripts/dist_projection.py [log2=22] [worlds=2,4,8] [reps=5] [modes=points,buckets] [knobs]
+
+knobs: "name:K=V,K=V;name2:K=V" -- every (mode, world) is timed once per knob set (environment knobs the
+       library reads per ctx / per proof), on the same resident key: same-box A/B of schedule variants
 
 modes: points  = MSMs cut by point range (rank 0 is timed: all ranks alike)
        buckets = witness-scalar MSMs cut by bucket range (every rank holds all A/B1/B2/L points; the
@@ -29,6 +32,11 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 worlds = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "2,4,8").split(",")]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 modes = (sys.argv[4] if len(sys.argv) > 4 else "points,buckets").split(",")
+knob_sets = [("default", {})]
+if len(sys.argv) > 5 and sys.argv[5]:
+    for item in sys.argv[5].split(";"):
+        name, _, kv = item.partition(":")
+        knob_sets.append((name, dict(x.split("=", 1) for x in kv.split(",") if x)))
 LINK_GBS = float(os.environ.get("G16_PROJ_LINK_GBS", "48"))   # one xGMI link, one direction, achieved
 t0 = time.time()
 mats, (A, B, Cm), w_ints, n_vars = bench.chain_circuit(cc, k)
@@ -68,7 +76,8 @@ xs = torch.cuda.Stream(priority=-1 if os.environ.get('G16_PROJ_XS_PRIO', '1') !=
 
 
 def one_rank(G, mode, rank):
-    p = cc.Prover(pk, mats, rank=rank, world=G, dist_wm=True, shard=mode)
+    p = cc.Prover(pk, mats, rank=rank, world=G, dist_wm=True, shard=mode,
+                  window_bits=int(os.environ.get("G16_PROJ_WINDOW_BITS", "0")))
     p.set_exchange_stream(xs.cuda_stream)
     nbytes = p.exchange_bytes()
     send = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
@@ -105,11 +114,17 @@ def one_rank(G, mode, rank):
 
 
 for mode in modes:
-    for G in worlds:
+  for G in worlds:
+    for kname, kenv in knob_sets:
+        for kk, vv in kenv.items():
+            os.environ[kk] = vv
         cand = [0] if mode == "points" else sorted({0, G // 2})
         res = [one_rank(G, mode, r) for r in cand]
+        for kk in kenv:
+            del os.environ[kk]
         tr, info, stages, sent, link_ms = max(res, key=lambda x: x[0])
-        out["ranks"][f"{mode}:{G}"] = {
+        out["ranks"][f"{mode}:{G}" + ("" if kname == "default" else ":" + kname)] = {
+            "knobs": kenv,
             "mode": mode, "G": G, "per_rank_ms": tr, "ranks_timed": {str(r): x[0] for r, x in zip(cand, res)},
             "efficiency_before_xgmi": t1 / (G * tr),
             "sent_MB_per_rank_per_proof": sent / 1e6, "link_ms_if_exposed": link_ms,

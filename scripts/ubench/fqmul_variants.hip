@@ -34,6 +34,23 @@ struct DpfConst {
   double ninv;   // -p^-1 mod 2^52
 };
 
+// FP64 operations as opaque instructions: LLVM's SIModeRegister pass re-asserts the DEFAULT rounding
+// mode (s_setreg ... FP_ROUND, 0) in front of every FP64 instruction it can see once a kernel has
+// touched the MODE register, which silently undoes set_rtz_f64() below (first version of this file:
+// 65535 of 65536 products wrong).  Inline asm is invisible to that pass; `volatile` keeps the
+// program order, so the independent operations of a row are written interleaved by hand.
+__device__ __forceinline__ double dfma(double a, double b, double c) {
+  double r;
+  asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ double dsub(double a, double b) {  // a - b
+  double r;
+  asm volatile("v_add_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double u52_to_d_rtz(uint64_t v) { return dsub(bitsd(v | 0x4330000000000000ull), 4503599627370496.0); }
+
 // a b / 2^260 mod p, result limbs < 2^52, value < 2p for inputs < 2^256.  Needs FP_ROUND(double) = RTZ.
 __device__ __forceinline__ D5 dpf_mul(const D5& a, const D5& b, const DpfConst& K) {
   const double C1 = 20282409603651670423947251286016.0;              // 2^104
@@ -49,27 +66,36 @@ __device__ __forceinline__ D5 dpf_mul(const D5& a, const D5& b, const DpfConst& 
   }
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
+    double hi[5], sb[5], lo[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) hi[j] = dfma(a.l[j], b.l[i], C1);       // floor(a b / 2^52) 2^52 + 2^104 (RTZ)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) sb[j] = dsub(C4, hi[j]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) lo[j] = dfma(a.l[j], b.l[i], sb[j]);    // (a b mod 2^52) + 2^52
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const double hi = __builtin_fma(a.l[j], b.l[i], C1);
-      const double lo = __builtin_fma(a.l[j], b.l[i], C4 - hi);
-      acc[i + j] += dbits(lo);
+      acc[i + j] += dbits(lo[j]);
       ++nlo[i + j];
-      acc[i + j + 1] += dbits(hi);
+      acc[i + j + 1] += dbits(hi[j]);
       ++nhi[i + j + 1];
     }
     // column i holds all of its a b terms and the q p terms of the earlier rows: q_i = -col / p mod 2^52
     const uint64_t col = acc[i] - (uint64_t)nlo[i] * BL - (uint64_t)nhi[i] * BH;
-    const double tl = u52_to_d(col & M52);
-    const double qh = __builtin_fma(tl, K.ninv, C1);
-    const double q = __builtin_fma(tl, K.ninv, C4 - qh) - 4503599627370496.0;  // low 52 bits of tl * ninv
+    const double tl = u52_to_d_rtz(col & M52);
+    const double qh = dfma(tl, K.ninv, C1);
+    const double q = dsub(dfma(tl, K.ninv, dsub(C4, qh)), 4503599627370496.0);  // low 52 bits of tl * ninv
+#pragma unroll
+    for (int j = 0; j < 5; ++j) hi[j] = dfma(q, K.p[j], C1);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) sb[j] = dsub(C4, hi[j]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) lo[j] = dfma(q, K.p[j], sb[j]);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const double hi = __builtin_fma(q, K.p[j], C1);
-      const double lo = __builtin_fma(q, K.p[j], C4 - hi);
-      acc[i + j] += dbits(lo);
+      acc[i + j] += dbits(lo[j]);
       ++nlo[i + j];
-      acc[i + j + 1] += dbits(hi);
+      acc[i + j + 1] += dbits(hi[j]);
       ++nhi[i + j + 1];
     }
     // column i is now 0 mod 2^52: carry the rest up
@@ -81,7 +107,7 @@ __device__ __forceinline__ D5 dpf_mul(const D5& a, const D5& b, const DpfConst& 
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const uint64_t col = acc[5 + k] - (uint64_t)nlo[5 + k] * BL - (uint64_t)nhi[5 + k] * BH + carry;
-    r.l[k] = u52_to_d(col & M52);
+    r.l[k] = u52_to_d_rtz(col & M52);
     carry = col >> 52;
   }
   return r;
@@ -89,7 +115,7 @@ __device__ __forceinline__ D5 dpf_mul(const D5& a, const D5& b, const DpfConst& 
 
 __device__ __forceinline__ void set_rtz_f64() {
   // MODE register (hwreg id 1), FP_ROUND[3:2] = double/half rounding: 3 = toward zero
-  __builtin_amdgcn_s_setreg(1 | (2 << 6) | ((2 - 1) << 11), 3);
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");
 }
 
 __device__ __forceinline__ D5 d5_from_words(const uint32_t (&w)[8]) {
