@@ -55,8 +55,8 @@ void shard(uint32_t len, int rank, int world, uint32_t* lo, uint32_t* hi) {
 
 // work1 keeps three partial-sum slots alive (A, B1, L accumulated before one batched reduction, or
 // reduced off the main stream) for small bucket sets and sharded ranks, two otherwise
-int work1_batch(const MsmConfig& cw, uint32_t wr) {
-  return (cw.nb() / wr < (1u << 18) || wr > 1 || getenv("G16_BATCH_REDUCE")) ? 3 : 2;
+int work1_batch(const MsmConfig& cw, uint32_t wr, bool sharded) {
+  return (cw.nb() / wr < (1u << 18) || sharded) ? 3 : 2;
 }
 
 // Device bytes the MSM state of one ctx takes for the configurations (cw: the four witness-scalar
@@ -64,7 +64,7 @@ int work1_batch(const MsmConfig& cw, uint32_t wr) {
 // arithmetic as the allocations in ctx_create_impl (MsmSort::bytes_for, msm_work_bytes).
 // own_w / own_h: false when the planes are borrowed from another ctx.
 size_t msm_state_bytes(const MsmConfig& cw, const MsmConfig& ch, uint32_t lw, uint32_t l_cnt, uint32_t lh,
-                       uint32_t wr, bool own_w, bool own_h) {
+                       uint32_t wr, bool sharded, bool own_w, bool own_h) {
   size_t b = 0;
   if (own_w) b += (size_t)cw.Pn * ((size_t)lw * (64 * 2 + 128) + (size_t)l_cnt * 64);
   if (own_h) b += (size_t)ch.Pn * lh * 64;
@@ -72,7 +72,7 @@ size_t msm_state_bytes(const MsmConfig& cw, const MsmConfig& ch, uint32_t lw, ui
   const uint32_t nc_w = ceil_div(cw.B, msm_red_chunk(cw, 1, wr)) * cw.D;
   const uint32_t nc_h = ceil_div(ch.B, msm_red_chunk(ch)) * ch.D;
   const uint32_t slots_w = cw.nb() + cw.max_lanes(), slots_h = ch.nb() + ch.max_lanes();
-  b += msm_work_bytes<Fq>(slots_w, nc_w, cw.D, work1_batch(cw, wr)) + msm_work_bytes<Fq2>(slots_w, nc_w, cw.D, 1) +
+  b += msm_work_bytes<Fq>(slots_w, nc_w, cw.D, work1_batch(cw, wr, sharded)) + msm_work_bytes<Fq2>(slots_w, nc_w, cw.D, 1) +
        msm_work_bytes<Fq>(slots_h, nc_h, ch.D, 1);
   return b;
 }
@@ -85,8 +85,8 @@ size_t msm_state_bytes(const MsmConfig& cw, const MsmConfig& ch, uint32_t lw, ui
 // against 70 % of the free memory and nothing else); what stays out is a margin of 2 GiB + 2 % for
 // allocator granularity and the runtime's own needs.  Domains the reference accepts (n <= 2^27,
 // qap.rs:30-32,63-68) are refused for memory only when not even ONE plane per point fits.
-void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_t lh, uint32_t wr, bool own_w,
-                      bool own_h, MsmConfig* cw, MsmConfig* ch) {
+void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_t lh, uint32_t wr, bool sharded,
+                      bool own_w, bool own_h, MsmConfig* cw, MsmConfig* ch) {
   if (own_w) *cw = msm_make_config(lw ? lw : 1, o.window_bits, o.planes);
   if (own_h) *ch = msm_make_config(lh ? lh : 1, o.window_bits, o.planes);
   if (o.planes > 0) return;  // the caller's choice: allocation failures are reported as such
@@ -94,7 +94,7 @@ void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) return;
   const size_t margin = ((size_t)2 << 30) + fr / 50;
   const size_t budget = fr > margin ? fr - margin : 0;
-  if (msm_state_bytes(*cw, *ch, lw, l_cnt, lh, wr, own_w, own_h) <= budget) return;  // full planes fit
+  if (msm_state_bytes(*cw, *ch, lw, l_cnt, lh, wr, sharded, own_w, own_h) <= budget) return;  // full planes fit
   // the distinct (D, Pn) layouts of each side, most planes first
   auto layouts = [&](const MsmConfig& full, uint32_t len, bool own) {
     std::vector<MsmConfig> v{full};
@@ -109,7 +109,7 @@ void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_
   size_t best_bytes = 0;
   for (const MsmConfig& a : vw)
     for (const MsmConfig& b : vh) {
-      const size_t need = msm_state_bytes(a, b, lw, l_cnt, lh, wr, own_w, own_h);
+      const size_t need = msm_state_bytes(a, b, lw, l_cnt, lh, wr, sharded, own_w, own_h);
       if (need > budget) continue;
       const long score = 5L * a.D + b.D;
       if (best < 0 || score < best || (score == best && need > best_bytes)) {
@@ -164,20 +164,23 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   ProofSums* S = c->sums_dev.p;
   if (!sorted) enqueue_witness_sort(c, w_dev);
-  // A/B knobs (measurement only): G16_BATCH_REDUCE / G16_B2_RED_STREAM = 0 | 1 override the size rules
-  // (read per proof, not once per process: scripts/dist_projection.py sweeps them over one resident key)
+  // G16_REDUCE_OFF_MAIN = 0 | 1 (measurement only) overrides the size rule of the schedule below; read
+  // per proof, not once per process: scripts/dist_projection.py sweeps it over one resident key
   auto env_int = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; };
-  const int knob_batch = env_int("G16_BATCH_REDUCE");
-  const int knob_b2 = env_int("G16_B2_RED_STREAM");
   // buckets this ctx reduces per MSM: 1/world of the set under bucket-range sharding
   const uint32_t nb_eff = c->cfg_w.nb() / (c->shard_buckets ? (uint32_t)c->world : 1u);
   const bool small = nb_eff < (1u << 18);
   const uint32_t b2_limit = c->world > 1 ? (1u << 18) : (1u << 16);
-  const bool b2_off = c->overlap && (knob_b2 < 0 ? nb_eff < b2_limit : knob_b2 != 0);
+  const bool b2_off = c->overlap && nb_eff < b2_limit;
   const int knob_off = env_int("G16_REDUCE_OFF_MAIN");
-  // bucket-sharded ranks: a reduction only occupies 1/world of the chip's wave slots, so it always
-  // leaves the main stream, whatever the size of the shared bucket set
-  const bool mid = (nb_eff >= (1u << 15) && small) || (c->shard_buckets && c->world > 1 && nb_eff >= (1u << 15));
+  // Sharded ranks (either cut): the reductions always leave the main stream, whatever the size of the
+  // bucket set.  A rank's chip is kept full by the distributed witness map on the aux stream, so a
+  // reduction on the main stream is exposed latency there while its work costs the same issue slots
+  // either way: one rank of 8 at 2^24 (2^19 buckets, point ranges), same box, medians of 7 proofs:
+  // 21.03 / 20.91 / 21.18 ms on the main stream, 20.57 / 20.64 ms off it (profiles/r04_proj_k24_knob_sweep2.json);
+  // one batched reduction of A, B1, L instead: 22.0 ms.
+  const bool sharded = c->world > 1 || c->dist_wm;
+  const bool mid = (nb_eff >= (1u << 15) && small) || (sharded && nb_eff >= (1u << 15));
   if ((knob_off < 0 ? mid : knob_off != 0) && c->overlap && c->work1.batch >= 3) {
     // Mid-sized bucket sets (2^15..2^17: 2^18..2^20-constraint proofs, ranks of a sharded 2^22
     // one): every reduction is a latency-bound chain long enough to matter and short enough to
@@ -192,23 +195,22 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     // stream it would sit between two accumulations and wait for a wave slot of a chip that the
     // red / aux streams keep busy (0.4 ms in a rank's timeline).  Same box, fix-up inline / on the
     // reducing stream: 2^20 proof 11.6-11.8 / 11.4 ms, one point-sharded rank of 8 at 2^22 7.9-8.0 / 7.8 ms
-    // (scripts/gpu_r3_run13.sh; G16_FIXUP_INLINE=1 is the A/B knob).
+    // (round 3, same box).
     hipStream_t q = c->red;
-    static const bool fix_inline = [] { const char* e = getenv("G16_FIXUP_INLINE"); return e && atoi(e) != 0; }();  // A/B knob
-    accumulate_ab(c, s, tm, /*fixup=*/fix_inline);
+    accumulate_ab(c, s, tm, /*fixup=*/false);
     G16_HIP(hipEventRecord(c->ev_acc[0], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[0], 0));
-    if (!fix_inline) fixup_ab(c, q);
+    fixup_ab(c, q);
     msm_reduce<Fq>(c->sort_w, c->work1, 0, 2, &S->A, q, tm, /*hidden=*/true);
     after_ab(q);
     msm_accumulate<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, 0, s, tm);
     G16_HIP(hipEventRecord(c->ev_acc[1], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[1], 0));
     msm_reduce<Fq2>(c->sort_w, c->work2, 0, 1, &S->B2, q, tm, /*hidden=*/true);
-    msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm, /*fixup=*/fix_inline);
+    msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm, /*fixup=*/false);
     G16_HIP(hipEventRecord(c->ev_acc[2], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[2], 0));
-    if (!fix_inline) msm_fixup<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, q, tm);
+    msm_fixup<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, q, tm);
     msm_reduce<Fq>(c->sort_w, c->work1, 2, 1, &S->L, q, tm, /*hidden=*/true);
     after_b2();
     G16_HIP(hipEventRecord(c->ev_b2, q));
@@ -216,7 +218,7 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     G16_HIP(hipEventRecord(c->ev_side, c->side));
     return;
   }
-  if ((knob_batch < 0 ? small : knob_batch != 0) && c->work1.batch >= 3) {
+  if (small && c->work1.batch >= 3) {
     // A, B1, L share the witness sort: three accumulations, ONE batched bucket reduction.  With
     // few buckets the reduction is pure latency (~0.4 ms of dependent EC additions whatever the
     // size): paying it once instead of three times is worth 20 % of a 2^16 proof and of a rank's
@@ -375,26 +377,15 @@ void rank_phase1_enqueue(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], 
   // The witness-scalar MSMs of this rank run on the main stream during both exchanges and phases
   // 2-3.  A persistent accumulation grid only hands wave slots to the aux stream when one of its
   // rounds retires, so phases 2-3 stretch fourfold underneath (profiles/r03_rank8_timeline_*).
-  // G16_MSM_AFTER_PHASE2=1 holds the first accumulation back until phase 2 is through (the sort still
-  // runs now, beside phase 1): the H MSM then never waits for its scalars, but the rank starts
-  // accumulating ~0.4 ms later -- same-box A/B at 2^22 / 8 ranks: 7.98 vs 7.76 ms, at 2^24 equal;
-  // off by default.
-  static const bool defer = [] { const char* e = getenv("G16_MSM_AFTER_PHASE2"); return e && atoi(e) != 0; }();
-  c->msm_deferred = defer;
-  c->w_cur = w_dev;
-  if (defer) enqueue_witness_sort(c, w_dev);
-  else enqueue_witness_msms(c, w_dev, [&](hipStream_t from) { fork_partial_var(c, from); }, [] {});
+  // (Holding the first accumulation back until phase 2 is through was measured in round 3 -- 7.98 vs
+  // 7.76 ms per rank at 2^22 / 8, equal at 2^24, profiles/r03_rank_schedule_ab.txt -- and removed.)
+  enqueue_witness_msms(c, w_dev, [&](hipStream_t from) { fork_partial_var(c, from); }, [] {});
 }
 
 void rank_phase2_enqueue(g16_ctx* c, const int32_t* recv_dev, int32_t* send_dev) {
   G16_HIP(hipSetDevice(c->device));
   c->wd.phase2(recv_dev, send_dev, c->aux);
   G16_HIP(hipEventRecord(c->ev_send, c->aux));
-  if (c->msm_deferred) {
-    c->msm_deferred = false;
-    G16_HIP(hipStreamWaitEvent(c->stream, c->ev_send, 0));
-    enqueue_witness_msms(c, c->w_cur, [&](hipStream_t from) { fork_partial_var(c, from); }, [] {}, /*sorted=*/true);
-  }
 }
 
 void rank_phase3_enqueue(g16_ctx* c, const int32_t* recv_dev) {
@@ -507,20 +498,9 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
   c->rank = o.rank;
   c->world = o.world;
   g16_status st = guarded(c, [&]() -> g16_status {
-    // G16_MSM_CU_RESERVE=n (measurement knob, sharded ranks): the main (MSM) stream may not use the
-    // first n CUs, so the witness-map chain on the aux stream never waits for a round of the
-    // persistent accumulation grid to retire
-    int cu_reserve = 0;
-    if (const char* e = getenv("G16_MSM_CU_RESERVE")) cu_reserve = atoi(e);
-#ifndef G16_EMU
-    if (cu_reserve > 0 && cu_reserve < 128) {
-      uint32_t mask[8];
-      for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
-      for (int i = 0; i < cu_reserve; ++i) mask[i >> 5] &= ~(1u << (i & 31));
-      G16_HIP(hipExtStreamCreateWithCUMask(&c->stream, 8, mask));
-    } else
-#endif
-      G16_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // (a CU mask that keeps the main stream off some CUs for the witness map was measured in rounds 2-3
+    // and changes nothing: the chip is issue bound, reserved CUs are lost to the accumulations)
+    G16_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     G16_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     G16_HIP(hipStreamCreateWithFlags(&c->red, hipStreamNonBlocking));
     {
@@ -528,9 +508,8 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       // ALU-bound MSM kernels: give its workgroups dispatch priority
       int lo = 0, hi = 0;
       G16_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      const char* pe = getenv("G16_AUX_PRIORITY");
-      const int want = pe ? atoi(pe) : 1;
-      G16_HIP(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, want ? hi : lo));
+      (void)lo;
+      G16_HIP(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
     }
     if (const char* e = getenv("G16_NO_OVERLAP")) c->overlap = !(e[0] == '1');
     G16_HIP(hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming));
@@ -638,7 +617,8 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     const uint32_t l_cnt = c->w_hi > l_first ? c->w_hi - l_first : 0;
     if (lender) c->cfg_w = lender->cfg_w;
     if (lend_h) c->cfg_h = lender->cfg_h;
-    plan_msm_configs(o, lw, l_cnt, lh, wr, !lender, !lend_h, &c->cfg_w, &c->cfg_h);
+    const bool sharded = c->world > 1 || c->dist_wm;
+    plan_msm_configs(o, lw, l_cnt, lh, wr, sharded, !lender, !lend_h, &c->cfg_w, &c->cfg_h);
     c->sort_w.init(lw, c->cfg_w);
     c->sort_w.set_shard(c->shard_buckets ? c->rank : 0, (int)wr);
     // A and B1 are gathered by the same (scalar, digit, bucket) entries: interleaved point by point,
@@ -685,7 +665,7 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       const uint32_t nc_w = ceil_div(c->cfg_w.B, msm_red_chunk(c->cfg_w, 1, wr)) * c->cfg_w.D;
       const uint32_t nc_h = ceil_div(c->cfg_h.B, msm_red_chunk(c->cfg_h)) * c->cfg_h.D;
       const uint32_t slots_w = c->cfg_w.nb() + c->cfg_w.max_lanes(), slots_h = c->cfg_h.nb() + c->cfg_h.max_lanes();
-      c->work1.init(slots_w, nc_w, c->cfg_w.D, work1_batch(c->cfg_w, wr));
+      c->work1.init(slots_w, nc_w, c->cfg_w.D, work1_batch(c->cfg_w, wr, sharded));
       c->workH.init(slots_h, nc_h, c->cfg_h.D, 1);
       c->work2.init(slots_w, nc_w, c->cfg_w.D);
     }

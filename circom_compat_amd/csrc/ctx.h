@@ -43,9 +43,6 @@ struct g16_ctx {
   // sharded provers: r/s-only finalisation sums already enqueued on the side stream by the
   // partial / phase-1 call for these (r, s)
   bool fixed_ready = false;
-  // phase 1 sorted the witness scalars only: phase 2 enqueues the witness MSMs (api.hip, rank_phase1_enqueue)
-  bool msm_deferred = false;
-  const g16::Fr* w_cur = nullptr;
   uint64_t fixed_rs[8] = {0};
   // Sharding of the MSMs over the ranks (options.shard):
   //   point ranges  -- rank g holds the points [w_lo, w_hi) / [h_lo, h_hi) of every query and its own

@@ -59,17 +59,11 @@ struct MsmConfig {
   uint32_t max_lanes() const { return lanes > lanes2 ? lanes : lanes2; }
 };
 
-// level-1 partition of the counting sort = bucket >> msm_part_shift(nb): at most 2^msm_part_bits()
-// partitions (G16_SORT_BINS = 6..10 overrides; every (sort block, partition) pair is one write
-// stream of the level-1 scatter, level 2 needs a partition to span <= 2048 buckets ... 4096 per chunk)
-inline int msm_part_bits() {
-  static const int bits = [] {
-    const char* e = getenv("G16_SORT_BINS");
-    const int v = e ? atoi(e) : 0;
-    return v >= 6 && v <= 10 ? v : 10;
-  }();
-  return bits;
-}
+// level-1 partition of the counting sort = bucket >> msm_part_shift(nb): at most 2^10 partitions (every
+// (sort block, partition) pair is one write stream of the level-1 scatter, level 2 needs a partition to
+// span <= 2048 buckets ... 4096 per chunk; 256 partitions: level 1 0.62 -> 0.48 ms, level 2 0.39 -> 0.61 ms
+// at 2^22, profiles/r03_sort_partition_ab.txt)
+inline int msm_part_bits() { return 10; }
 inline int msm_part_shift(uint32_t nb) {
   int bits = 0;
   while (((uint64_t)1 << bits) < nb) ++bits;
@@ -89,24 +83,13 @@ inline int msm_part_shift(uint32_t nb) {
 // on that one stream and the variable-base products wait for the first of them.  Measured on one box
 // (scripts/gpu_r3_run13.sh; 2^20 proof / one rank of 8 at 2^22, ms): 65536 threads 11.4-11.8 / 7.8-8.0,
 // 16384 threads 11.5-11.9 / 7.7-8.1, 8192 threads 12.4-12.5 / 8.9-9.1 -- the narrow reductions finish
-// after the last accumulation.  So hidden reductions keep the exposed width; G16_RED_LANES_HIDDEN overrides.
+// after the last accumulation.  So hidden reductions keep the exposed width.
 inline uint32_t msm_red_chunk(const MsmConfig& cfg, uint32_t nbatch = 1, uint32_t world = 1, bool hidden = false) {
-  static const uint32_t lanes_exposed = [] {
-    const char* e = getenv("G16_RED_LANES");  // tuning knob: threads the reduction aims for
-    return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 65536u;
-  }();
-  static const uint32_t lanes_hidden = [] {
-    const char* e = getenv("G16_RED_LANES_HIDDEN");
-    return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 65536u;
-  }();
-  const uint32_t lanes_target = hidden ? lanes_hidden : lanes_exposed;
+  (void)hidden;  // hidden reductions keep the exposed width: 65536 threads either way (measured above)
+  const uint32_t lanes_target = 65536u;
   uint32_t ch = (uint32_t)(((uint64_t)nbatch * cfg.D * cfg.B) / ((uint64_t)lanes_target * (world ? world : 1)));
   if (ch < 1) ch = 1;
-  static const uint32_t ch_max = [] {
-    const char* e = getenv("G16_RED_MAX");
-    return e && atoi(e) > 0 ? (uint32_t)atoi(e) : (uint32_t)MSM_RED_CHUNK;
-  }();
-  if (ch > ch_max) ch = ch_max;
+  if (ch > (uint32_t)MSM_RED_CHUNK) ch = (uint32_t)MSM_RED_CHUNK;
   if (world > 1) {  // largest power of two <= ch, <= 2^(partition shift)
     uint32_t p2 = 1;
     while (p2 * 2 <= ch) p2 *= 2;

@@ -27,11 +27,10 @@ inline bool acc_fast() {
   static const bool v = [] { const char* e = getenv("G16_ACC_FAST"); return !e || atoi(e) != 0; }();
   return v;
 }
-// G16_ACC_FAST_G2=1: the optimistic kernel for the G2 launch as well (measured: see DESIGN.md section 5)
-inline bool acc_fast_g2() {
-  static const bool v = [] { const char* e = getenv("G16_ACC_FAST_G2"); return e && atoi(e) != 0; }();
-  return v;
-}
+// (the optimistic kernel for the G2 launch was built and measured in round 3: 13.5-13.7 against
+// 12.2-12.3 ms per launch, DESIGN.md section 5 -- G2 keeps the exact kernel, the variant is not compiled)
+template <class F>
+constexpr bool acc_is_g1() { return sizeof(F) == sizeof(Fq); }
 constexpr int COMB_THREADS = 64;
 constexpr int SUM_THREADS = 128;
 
@@ -573,18 +572,20 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
   MsmAcc<F>* out = work.partial.p + (size_t)slot * work.slots;
   const uint32_t* en = (const uint32_t*)s.entries.p;
   const uint32_t* of = (const uint32_t*)s.offset.p;
-  if (sizeof(F) == sizeof(Fq) ? acc_fast() : acc_fast_g2()) {
-    // optimistic kernel; the deferred exact additions follow (msm_fixup), here or on the reducing stream
-    MsmFixList* fix = work.fix.p + slot;
-    if (P.stride == 2)
-      G16_LAUNCH((k_bucket_accumulate<F, 2, false, true>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
-                 P.count, idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, fix);
-    else
-      G16_LAUNCH((k_bucket_accumulate<F, 1, false, true>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
-                 idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, fix);
-    if (tm) tm->end(id, stream);
-    if (fixup) msm_fixup<F>(s, P, idx_min, work, slot, stream, tm);
-    return;
+  if constexpr (acc_is_g1<F>()) {
+    if (acc_fast()) {
+      // optimistic kernel; the deferred exact additions follow (msm_fixup), here or on the reducing stream
+      MsmFixList* fix = work.fix.p + slot;
+      if (P.stride == 2)
+        G16_LAUNCH((k_bucket_accumulate<F, 2, false, true>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
+                   P.count, idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, fix);
+      else
+        G16_LAUNCH((k_bucket_accumulate<F, 1, false, true>), grid, ACC_THREADS, 0, stream, P.data(), P.count,
+                   idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, fix);
+      if (tm) tm->end(id, stream);
+      if (fixup) msm_fixup<F>(s, P, idx_min, work, slot, stream, tm);
+      return;
+    }
   }
   if (P.stride == 2)
     G16_LAUNCH((k_bucket_accumulate<F, 2, false, false>), grid, ACC_THREADS, 0, stream, P.data() + P.off,
@@ -598,7 +599,10 @@ void msm_accumulate(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, M
 template <class F>
 void msm_fixup(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWork<F>& work, int slot,
                hipStream_t stream, StageTimer* tm) {
-  if (!(sizeof(F) == sizeof(Fq) ? acc_fast() : acc_fast_g2())) return;
+  if constexpr (!acc_is_g1<F>()) {
+    return;  // the G2 launch is the exact kernel: nothing was set aside
+  } else {
+  if (!acc_fast()) return;
   const int tid = tm ? tm->begin(ST_MSM_FIXUP, stream) : -1;
   const MsmConfig& cfg = s.cfg;
   const uint32_t nb = cfg.nb();
@@ -626,6 +630,7 @@ void msm_fixup(const MsmSort& s, const MsmPoints<F>& P, uint32_t idx_min, MsmWor
                idx_min, cfg.idx_bits, en, of, nb, lanes, out, (size_t)0, fix);
   }
   if (tm) tm->end(tid, stream);
+  }
 }
 
 template <class F>

@@ -498,18 +498,13 @@ __global__ void __launch_bounds__(256) k_find_large(const uint32_t* offset, uint
 }  // namespace
 
 
-// workgroups of the sort kernels (G16_SORT_GRID overrides)
+// workgroups of the sort kernels
 static uint32_t sort_grid_cap() {
-  static const uint32_t cap = [] {
-    const char* e = getenv("G16_SORT_GRID");
-    const int v = e ? atoi(e) : 0;
 #ifdef G16_EMU
-    return v > 0 && v <= 8192 ? (uint32_t)v : 32u;  // emulator: every thread of a launch is stepped through
+  return 32u;  // emulator: every thread of a launch is stepped through
 #else
-    return v > 0 && v <= 8192 ? (uint32_t)v : 2048u;
+  return 2048u;
 #endif
-  }();
-  return cap;
 }
 
 void MsmSort::set_shard(int rank_, int world_) {

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of a round-4 measurement run: G16_DEFER_L_RED / G16_BATCH_REDUCE were knobs of the library AT THAT COMMIT and were
+# removed once measured -- profiles/r04_defer_l_reduction_ab.txt, profiles/r04_proj_k24_knob_sweep*.json)
 # round 4, GPU run 1: (a) parity subset on the new sort-entry layout / memory plan / self-test,
 # (b) fqmul variants microbenchmark, (c) same-box A/B of the deferred L reduction, (d) clock trace with
 # HBM gathers vs cache-resident gathers (-DG16_DEBUG_GATHER variant), (e) 2^26 constraints on one GPU.

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of a round-4 measurement run: G16_DEFER_L_RED / G16_BATCH_REDUCE were knobs of the library AT THAT COMMIT and were
+# removed once measured -- profiles/r04_defer_l_reduction_ab.txt, profiles/r04_proj_k24_knob_sweep*.json)
 # round 4, GPU run 2: (a) parity subset on the CURRENT library (self-test, overflow path, key-generator
 # pin, planes < W at 2^22), (b) fqmul variants (DPF product with opaque FP instructions),
 # (c) deferred L reduction same-box A/B at 2^22, (d) one rank of 8 at 2^24: schedule knob sweep on one key
