@@ -879,7 +879,13 @@ def main():
     if parts:
         out["parts_ms"] = parts
     if cpu:
-        out["gpu_over_cpu"] = out["value"] / cpu["value"]
+        # a prove() caller hands over a HOST witness: the ratio that compares like with like is the
+        # PCIe-inclusive step over the CPU restatement; the resident-witness ratio beside it
+        if out["value_pcie_inclusive"]:
+            out["gpu_over_cpu"] = out["value_pcie_inclusive"] / cpu["value"]
+            out["gpu_over_cpu_note"] = ("PCIe-inclusive GPU step (host witness -> proof) / CPU restatement, the CPU side on "
+                                        f"{cpu['cores']} threads with MSMs {cpu['msm_parallelism']} threads wide; a baseline, not a kernel-quality figure")
+        out["gpu_resident_over_cpu"] = out["value"] / cpu["value"]
     print(json.dumps(out), flush=True)
     if zkey_path and os.path.exists(zkey_path):
         os.remove(zkey_path)
