@@ -91,6 +91,13 @@ __device__ __forceinline__ void acc_fetch(const Affine<F>* __restrict__ pts, uin
     const uint32_t plane = (en & 0x7fffffffu) >> idx_bits;
 #ifdef G16_DEBUG_GATHER
     raw = pts[((size_t)(plane & g_gather_mask) * npts + ((idx - idx_min) & g_gather_mask)) * PS];
+#elif defined(G16_NT_GATHER)
+    // experiment (round 4): non-temporal loads for the single-use point gathers
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u* src = reinterpret_cast<const v4u*>(&pts[((size_t)plane * npts + (idx - idx_min)) * PS]);
+    v4u* dst = reinterpret_cast<v4u*>(&raw);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(Affine<F>) / 16); ++k) dst[k] = __builtin_nontemporal_load(src + k);
 #else
     raw = pts[((size_t)plane * npts + (idx - idx_min)) * PS];
 #endif

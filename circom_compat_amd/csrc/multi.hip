@@ -359,6 +359,14 @@ void multi_selftest(Multi& M) {
     }
     G16_HIP(hipStreamSynchronize(c->aux));
     G16_HIP(hipMemcpy(host[g].data(), bad[g]->p, 3 * (size_t)G * 4, hipMemcpyDeviceToHost));
+  });
+  // a stage of its own: the first device has finished gathering (it synchronised in the stage above)
+  // before any rank clears the record it was read from -- with the clean-up inside the gather stage a
+  // fast rank zeroed its record under the gather's peer copy (seen once on the GPU, never on the
+  // emulator, whose stages run device after device)
+  st.push_back([&](int g) {
+    g16_ctx* c = M.ch[g];
+    G16_HIP(hipSetDevice(c->device));
     // leave the buffers as a fresh ctx has them
     G16_HIP(hipMemsetAsync(c->out_dev.p, 0, c->out_dev.bytes(), c->stream));
     G16_HIP(hipStreamSynchronize(c->stream));
