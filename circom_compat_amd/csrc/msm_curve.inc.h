@@ -83,6 +83,9 @@ __device__ uint32_t g_gather_mask = 0xffffffffu;
 
 // pts already points at this query's half of an interleaved pair; PS = record stride in points
 template <class F, int PS>
+// (round 4: non-temporal loads for these single-use gathers -- __builtin_nontemporal_load per 16-byte piece --
+// were measured on a variant build: 39.17 / 38.96 / 39.24 against 37.64 / 37.78 / 37.41 ms per 2^22 proof, the G2
+// launch 14.3 against 12.7 ms: the pieces of a point stop sharing the line their first miss brought in.  Not kept.)
 __device__ __forceinline__ void acc_fetch(const Affine<F>* __restrict__ pts, uint32_t npts,
                                           uint32_t idx_min, uint32_t idx_bits, uint32_t en,
                                           Affine<F>& raw) {
@@ -91,13 +94,6 @@ __device__ __forceinline__ void acc_fetch(const Affine<F>* __restrict__ pts, uin
     const uint32_t plane = (en & 0x7fffffffu) >> idx_bits;
 #ifdef G16_DEBUG_GATHER
     raw = pts[((size_t)(plane & g_gather_mask) * npts + ((idx - idx_min) & g_gather_mask)) * PS];
-#elif defined(G16_NT_GATHER)
-    // experiment (round 4): non-temporal loads for the single-use point gathers
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    const v4u* src = reinterpret_cast<const v4u*>(&pts[((size_t)plane * npts + (idx - idx_min)) * PS]);
-    v4u* dst = reinterpret_cast<v4u*>(&raw);
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(Affine<F>) / 16); ++k) dst[k] = __builtin_nontemporal_load(src + k);
 #else
     raw = pts[((size_t)plane * npts + (idx - idx_min)) * PS];
 #endif
