@@ -510,6 +510,30 @@ def main():
             recv = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         part_t = cc.device_tensor(prover.partial_buffer(), 1024, dev)
         gath_t = cc.device_tensor(prover.gather_buffer(), world * 1024, dev)
+
+        # (round 4: these two definitions had been deleted by mistake in round 3 together with the h
+        # all-gather -- the per-process path, i.e. G16_BENCH_MODE=ranks AND the fallback behind a failed
+        # in-library ctx, died with a NameError; scripts/r4_nshape.sh now runs both shapes every round)
+        def exchange():
+            with torch.cuda.stream(xs):
+                if backend == "nccl":
+                    dist.all_to_all_single(recv, send, group=grp)
+                else:
+                    xs.synchronize()
+                    hs, hr = send.cpu(), torch.empty(nbytes, dtype=torch.uint8)
+                    dist.all_to_all_single(hr, hs)
+                    recv.copy_(hr)
+
+        def gather():
+            with torch.cuda.stream(xs):
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(gath_t, part_t, group=grp)
+                else:
+                    xs.synchronize()
+                    parts = [torch.empty(1024, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(parts, part_t.cpu())
+                    gath_t.copy_(torch.cat(parts))
+
     def step():
         if mode in ("single", "inlib"):
             return prover.prove_dev(rs[0], rs[1], w_ptr)

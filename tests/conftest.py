@@ -41,6 +41,11 @@ def golden():
 @pytest.fixture(scope="session")
 def emu():
     """Kernel sources built against the CPU SIMT emulator (tests only)."""
+    # G16_EMU_LIB: another build of the same emulator library (scripts/asan_emu.sh: the kernels under
+    # AddressSanitizer -- device memory is host malloc there, so an out-of-bounds kernel access is a report)
+    if os.environ.get("G16_EMU_LIB"):
+        from circom_compat_amd import _binding
+        return _binding.Library(os.environ["G16_EMU_LIB"])
     so = os.path.join(ROOT, "tests", "emu", "libg16_emu.so")
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "circom_compat_amd", "csrc"), "emu", "-j8"],
                        capture_output=True, text=True)

@@ -1,0 +1,44 @@
+"""The driver's N > 1 launch shapes of bench.py, functionally, on ONE GPU (the ranks time-share device 0,
+gloo instead of RCCL between the processes): the in-library ctx under torch.distributed.run, the
+fallback to one ctx per process when the in-library ctx cannot be built, and the per-process path asked
+for directly.  Round 3 shipped with the per-process path dead (two helpers deleted by mistake: NameError)
+because nothing in the suites ran it; these do.  Every line must carry a pairing-verified proof that is
+byte-identical to the CPU restatement's at the probe size."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(n, port, extra_env, log2=14):
+    env = dict(os.environ)
+    env.update({"G16_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "TMPDIR": "/tmp"})
+    env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(n), "--log2", str(log2), "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line), r.stderr
+
+
+@pytest.mark.parametrize("name,n,env", [("inlib", 2, {}), ("fallback", 2, {"G16_BENCH_FAIL_INLIB": "1"}),
+                                        ("ranks", 4, {"G16_BENCH_MODE": "ranks"})])
+def test_bench_n_gt_1_shapes_on_one_gpu(gpulib, name, n, env):
+    d, err = _run(n, 29531 + n + len(name), env)
+    assert d["n_gpus"] == n and d["scaling"] == "strong" and d["value"] > 0
+    assert d["parity"]["proof_verifies"] and d["parity"]["wrong_public_input_rejected"]
+    assert all(v for k, v in d["parity"].items() if k.startswith("bit_identical_to_cpu")), d["parity"]
+    par = d["config"]["parallelism"]
+    if name == "inlib":
+        assert "g16_ctx_create_multi" in par and not d.get("fallback_reason")
+    elif name == "fallback":
+        assert d.get("fallback_reason") and "one process per GPU" in par and "fallback" in par, (par, d.get("fallback_reason"))
+    else:
+        assert "one process per GPU" in par and "g16_ctx_create_multi" not in par, par

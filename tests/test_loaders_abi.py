@@ -209,3 +209,42 @@ def test_zkey_copy_mode_survives_a_file_rewritten_under_the_handle(gpulib, golde
     env = dict(os.environ, G16_ZKEY_COPY="1", G16_NO_TORCH_PRELOAD="1", PYTHONPATH=os.pathsep.join(sys.path))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_python_sources_have_no_undefined_names():
+    """bench.py's per-process N > 1 path called two helpers (`exchange`, `gather`) whose definitions had
+    been deleted in round 3: a NameError that only a run on that path -- never exercised by the suites --
+    could show.  A coarse static check closes that class: every name that is LOADED anywhere in a module
+    must be BOUND somewhere in it (any scope), or be a builtin."""
+    import ast
+    import builtins
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    for pat in ("circom_compat_amd/*.py", "scripts/*.py", "oracle/*.py", "tests/helpers.py", "tests/golden/*.py"):
+        files += sorted(glob.glob(os.path.join(root, pat)))
+    assert len(files) > 10
+    for path in files:
+        tree = ast.parse(open(path).read(), path)
+        bound = set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+        for n in ast.walk(tree):
+            if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                bound.add(n.name)
+            if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.Lambda)):
+                a = n.args
+                for x in a.args + a.kwonlyargs + a.posonlyargs:
+                    bound.add(x.arg)
+                for x in (a.vararg, a.kwarg):
+                    if x:
+                        bound.add(x.arg)
+            if isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                bound.add(n.id)
+            if isinstance(n, (ast.Import, ast.ImportFrom)):
+                for al in n.names:
+                    bound.add((al.asname or al.name).split(".")[0])
+            if isinstance(n, ast.ExceptHandler) and n.name:
+                bound.add(n.name)
+            if isinstance(n, (ast.Global, ast.Nonlocal)):
+                bound.update(n.names)
+        used = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+        assert not (used - bound), "%s: names used but never bound: %r" % (os.path.relpath(path, root), sorted(used - bound))
