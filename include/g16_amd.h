@@ -117,7 +117,13 @@ enum { G16_QUERY_A = 0, G16_QUERY_B1 = 1, G16_QUERY_L = 2, G16_QUERY_H = 3 };
 
 /* Uploads the key and the matrices once, precomputes NTT tables and MSM point planes.
  * Replaces: holding `(ProvingKey<Bn254>, ConstraintMatrices<Fr>)` from read_zkey (src/zkey.rs:53-60)
- * across calls.  num_constraints = matrices.num_constraints (src/zkey.rs:171).                    */
+ * across calls.  num_constraints = matrices.num_constraints (src/zkey.rs:171).
+ * Sizes: every domain the reference accepts is accepted -- G16_ERR_DOMAIN_TOO_LARGE exactly where
+ * CircomReduction raises PolynomialDegreeTooLarge (num_constraints + num_inputs > 2^27: no 2n-domain,
+ * src/circom/qap.rs:30-32,63-68).  The point planes are planned against the device memory that is free
+ * at the call: full precomputation up to 2^25 constraints on a 288 GB device, fewer planes (more bucket
+ * sets per MSM, same results) above; G16_ERR_INTERNAL "does not fit this device's memory even with
+ * one plane per point" only when nothing fits.  opt->planes > 0 overrides the plan.               */
 g16_status g16_ctx_create(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
                           uint32_t num_constraints, const g16_options* opt, g16_ctx** out);
 void g16_ctx_destroy(g16_ctx* ctx);
@@ -144,7 +150,12 @@ const char* g16_last_error(const g16_ctx* ctx); /* ctx may be NULL: error of the
  * opt->device / rank / world / dist_wm are ignored (dist_wm < 0 forces a replicated witness map).
  * device_ids may repeat an ordinal (several ranks time-sharing one GPU: functional tests).
  * Direct peer access between the devices is requested and REPORTED (g16_ctx_info out[14]; one line on
- * stderr when the runtime will stage copies; G16_REQUIRE_PEER_ACCESS=1 makes that an error).        */
+ * stderr when the runtime will stage copies; G16_REQUIRE_PEER_ACCESS=1 makes that an error).
+ * Creation ends with a self-test of every peer path (a 4 KiB-per-pair all-to-all echo and a gather of
+ * the partial records through the copy streams, events and buffers a proof uses, known patterns
+ * checked on the devices): a path that does not deliver what was sent is an ERROR here (G16_ERR_HIP,
+ * g16_last_error(NULL) names the exchange and the source / destination ranks and devices), never a
+ * wrong proof later.                                                                                */
 g16_status g16_ctx_create_multi(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
                                 uint32_t num_constraints, const int* device_ids, int n_dev,
                                 const g16_options* opt, g16_ctx** out);
@@ -225,7 +236,10 @@ g16_status g16_prove_dist_phase3(g16_ctx* ctx, const void* recv_dev,
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
 #define G16_N_STAGES 8
 g16_status g16_set_profiling(g16_ctx* ctx, int enabled);
-/* HIP-event times accumulated since the last call; resets the accumulators.                       */
+/* HIP-event times accumulated since the last call; resets the accumulators.  Stages, in order:
+ * witness_map, msm_sort, msm_accumulate_g1 (L, H), msm_accumulate_g2 (B2), msm_reduce, finalize,
+ * msm_accumulate_g1_pair (A | B1 in one launch), msm_fixup (the exact additions behind an optimistic
+ * G1 launch); g16_stage_name() returns the same strings.                                            */
 g16_status g16_stage_times(g16_ctx* ctx, float ms[G16_N_STAGES], uint32_t launches[G16_N_STAGES]);
 const char* g16_stage_name(int stage);
 /* sizes chosen at create time: out[0]=c_w out[1]=W_w out[2]=planes_w out[3]=D_w, [4..7] same for H,
