@@ -152,7 +152,7 @@ g16_status g16_setup_create_ex(int device, const g16_csr* at, const g16_csr* bt,
     const uint32_t num_inputs = n_public + 1, m = num_constraints, N = n_vars;
     int k = 0;
     while (((uint64_t)1 << k) < (uint64_t)m + num_inputs) ++k;
-    if (k + 1 > 27) throw std::runtime_error("PolynomialDegreeTooLarge");
+    if (k + 1 > 28) throw std::runtime_error("PolynomialDegreeTooLarge");  // the prover's own limit (qap.rs:63-68): n <= 2^27
     const uint32_t n = 1u << k;
     S->n_vars = N;
     S->n_public = n_public;

@@ -59,15 +59,23 @@ struct MsmConfig {
   uint32_t max_lanes() const { return lanes > lanes2 ? lanes : lanes2; }
 };
 
-// level-1 partition of the counting sort = bucket >> msm_part_shift(nb): at most 2^10 partitions (every
-// (sort block, partition) pair is one write stream of the level-1 scatter, level 2 needs a partition to
-// span <= 2048 buckets ... 4096 per chunk; 256 partitions: level 1 0.62 -> 0.48 ms, level 2 0.39 -> 0.61 ms
-// at 2^22, profiles/r03_sort_partition_ab.txt)
-inline int msm_part_bits() { return 10; }
+// level-1 partition of the counting sort = bucket >> msm_part_shift(nb): 2^10 partitions (every (sort
+// block, partition) pair is one write stream of the level-1 scatter; 256 partitions: level 1 0.62 -> 0.48 ms,
+// level 2 0.39 -> 0.61 ms at 2^22, profiles/r03_sort_partition_ab.txt) -- more only where level 2 needs
+// them: its LDS histogram holds 4096 buckets per chunk, and a partition that spans more falls back to one
+// global atomic per ENTRY (seen at 2^27 on one GPU: 3 bucket sets of 2^21 = 6144 buckets per partition,
+// both sorts 346 ms instead of ~90).  So 2^11 / 2^12 partitions once the bucket sets exceed 2^22 / 2^23.
+constexpr int MSM_PART_BITS_MAX = 12;
+inline int msm_part_bits(uint32_t nb) {
+  int bits = 10;
+  while (bits < MSM_PART_BITS_MAX && (((uint64_t)nb + ((uint64_t)1 << bits) - 1) >> bits) > 4096u) ++bits;
+  return bits;
+}
 inline int msm_part_shift(uint32_t nb) {
   int bits = 0;
   while (((uint64_t)1 << bits) < nb) ++bits;
-  return bits > msm_part_bits() ? bits - msm_part_bits() : 0;
+  const int pb = msm_part_bits(nb);
+  return bits > pb ? bits - pb : 0;
 }
 
 // buckets per thread of k_bucket_reduce.  The kernel is a serial chain of ~3 EC additions per bucket
@@ -174,7 +182,14 @@ struct MsmPoints {
 // Mixed additions the optimistic accumulation kernel set aside (its x-coordinate filter fired:
 // acc = +-P is possible): (slot of the partial sum the addition belongs to, sort entry).  A list that
 // overflows marks the launch for the exact kernel.
-constexpr uint32_t MSM_FIX_CAP = 512;
+// ~2^-22.7 of the mixed additions are set aside (the filter's false positives): 6 per launch at 2^22, 242 per
+// single-query launch and 484 per pair launch at 2^27 -- where a 512-entry list overflowed in one proof of
+// two and the exact kernel redid a 270 ms launch (profiles/r04_bench_chain27.json, first run)
+#ifdef G16_EMU
+constexpr uint32_t MSM_FIX_CAP = 512;  // emulator: keeps the overflow test small
+#else
+constexpr uint32_t MSM_FIX_CAP = 2048;
+#endif
 struct MsmFixList {
   uint32_t count;     // appended by k_bucket_accumulate<.., FAST>, reset by k_acc_fixup
   uint32_t overflow;  // written by k_acc_fixup: the exact kernel behind it redoes the whole launch

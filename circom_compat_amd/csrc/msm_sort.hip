@@ -149,7 +149,7 @@ __device__ __forceinline__ void for_each_digit(const U256& scalar, uint32_t i, i
 // Order inside a bucket is arbitrary (EC addition commutes), which is what makes atomics-based
 // ranks admissible.  The outputs (count, offset, entries) are those of the single-level sort.
 constexpr int P1_THREADS = 256, P1_PER_THREAD = 8, P1_TILE = P1_THREADS * P1_PER_THREAD;
-constexpr int P1_MAX_BINS = 1024;
+constexpr int P1_MAX_BINS = 1 << MSM_PART_BITS_MAX;  // LDS histogram / cursor array of the level-1 passes
 constexpr int P2_THREADS = 256, P2_CHUNK = 16384, P2_BINS = 4096;
 
 struct SortGeom {
@@ -525,9 +525,10 @@ void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   const uint64_t M = (uint64_t)cap * cfg.W;
   if (M >= ((uint64_t)1 << 32)) throw std::runtime_error("MSM entry count exceeds 2^32");
   part.alloc(M ? M : 1);
-  part_off.alloc(P1_MAX_BINS + 1);
-  blk_hist.alloc((size_t)P1_MAX_BINS * sort_grid_cap() + 1);
-  blk_off.alloc((size_t)P1_MAX_BINS * sort_grid_cap() + 1);
+  const size_t bins1 = (size_t)1 << msm_part_bits(nb);
+  part_off.alloc(bins1 + 1);
+  blk_hist.alloc(bins1 * sort_grid_cap() + 1);
+  blk_off.alloc(bins1 * sort_grid_cap() + 1);
   count.alloc((size_t)nb + 1);
   offset.alloc((size_t)nb + 1);
   cursor.alloc((size_t)nb + 1);
@@ -537,17 +538,18 @@ void MsmSort::init(uint32_t capacity, const MsmConfig& c) {
   meta.alloc(4);
   multi_l2.alloc((size_t)(M / ((uint64_t)MSM_MIN_SEG * MSM_SMALL_MULTI)) + 2);
   meta2.alloc(4);
-  const uint64_t scan_len = std::max<uint64_t>((uint64_t)nb + 1, (uint64_t)P1_MAX_BINS * sort_grid_cap() + 1);
+  const uint64_t scan_len = std::max<uint64_t>((uint64_t)nb + 1, (uint64_t)bins1 * sort_grid_cap() + 1);
   scan_tmp.alloc(ceil_div(scan_len, SCAN_TILE) + 1);
 }
 
 size_t MsmSort::bytes_for(uint32_t capacity, const MsmConfig& cfg) {
   const uint64_t M = std::max<uint64_t>((uint64_t)capacity * cfg.W, 1);
   const uint64_t nb = cfg.nb();
-  const uint64_t hist = (uint64_t)P1_MAX_BINS * sort_grid_cap() + 1;
+  const uint64_t bins1 = (uint64_t)1 << msm_part_bits((uint32_t)nb);
+  const uint64_t hist = bins1 * sort_grid_cap() + 1;
   const uint64_t large = M / ((uint64_t)MSM_MIN_SEG * MSM_SMALL_MULTI) + 2;
   return (size_t)(M * sizeof(MsmPair) + M * 4 + 3 * (nb + 1) * 4 + 2 * hist * 4 + 2 * large * 4 +
-                  (ceil_div(std::max<uint64_t>(nb + 1, hist), SCAN_TILE) + 1) * 4 + (P1_MAX_BINS + 1) * 4 + 64);
+                  (ceil_div(std::max<uint64_t>(nb + 1, hist), SCAN_TILE) + 1) * 4 + (bins1 + 1) * 4 + 64);
 }
 
 size_t MsmSort::device_bytes() const {

@@ -241,7 +241,11 @@ Fr fr_root_of_unity(int log_n) {
 }
 
 void NttPlan::build(int log_n) {
-  if (log_n < 0 || log_n > 27) throw std::runtime_error("NTT size out of range (need 2n-th root)");
+  // k = 28 (the whole two-adic subgroup of Fr) serves the key generator's one transform of size 2n at
+  // n = 2^27 -- the largest domain the reference accepts; such a plan has no omega_2n coset twist
+  // (no 2^29-th root exists) and ntt_dif refuses NTT_FUSE_TWIST_SCALE on it.  The witness map needs the
+  // twist and therefore stops at k = 27 (witness_map.hip: PolynomialDegreeTooLarge, as qap.rs:63-68).
+  if (log_n < 0 || log_n > 28) throw std::runtime_error("NTT size out of range (Fr has two-adicity 28)");
   k = log_n;
   n = (size_t)1 << k;
   passes.clear();
@@ -269,7 +273,7 @@ void NttPlan::build(int log_n) {
 
   const Fr w = fr_root_of_unity(k);
   const Fr winv = w.inv();
-  const Fr w2n = fr_root_of_unity(k + 1);
+  const Fr w2n = k < 28 ? fr_root_of_unity(k + 1) : Fr::one();
   Fr nn = Fr::from_u32(1);
   {  // n as a field element
     U256 u;
@@ -301,11 +305,13 @@ void NttPlan::build(int log_n) {
     G16_HIP(hipMemcpy(tlo[d].p, hlo.data(), nlo * sizeof(Fr), hipMemcpyHostToDevice));
     G16_HIP(hipMemcpy(thi[d].p, hhi.data(), nhi * sizeof(Fr), hipMemcpyHostToDevice));
   }
-  fill(w2n, n_inv);
-  twlo.alloc(nlo);
-  twhi.alloc(nhi);
-  G16_HIP(hipMemcpy(twlo.p, hlo.data(), nlo * sizeof(Fr), hipMemcpyHostToDevice));
-  G16_HIP(hipMemcpy(twhi.p, hhi.data(), nhi * sizeof(Fr), hipMemcpyHostToDevice));
+  if (k < 28) {
+    fill(w2n, n_inv);
+    twlo.alloc(nlo);
+    twhi.alloc(nhi);
+    G16_HIP(hipMemcpy(twlo.p, hlo.data(), nlo * sizeof(Fr), hipMemcpyHostToDevice));
+    G16_HIP(hipMemcpy(twhi.p, hhi.data(), nhi * sizeof(Fr), hipMemcpyHostToDevice));
+  }
 
   const size_t nloc = (size_t)1 << (loc_bits - 1);
   std::vector<Fr> hl(nloc);
@@ -324,6 +330,7 @@ void NttPlan::build(int log_n) {
 
 void ntt_dif(const NttPlan& P, Fr* data, size_t stride, int batch, bool inverse, NttFuse fuse,
              hipStream_t stream) {
+  if (fuse == NTT_FUSE_TWIST_SCALE && !P.twlo.p) throw std::runtime_error("NTT plan of size 2^28 has no coset twist");
   if (P.k == 0) return;
   for (size_t i = 0; i < P.passes.size(); ++i) {
     const bool last = (i + 1 == P.passes.size());

@@ -205,13 +205,15 @@ def test_msm_hot_bucket_split(lib):
 def test_optimistic_accumulation_overflow_falls_back_to_the_exact_kernel(lib):
     """A key whose query points are ALL the same point and a witness of ones: every mixed addition after a
     lane's first is acc + P with acc = P, i.e. the x-coordinates coincide, the optimistic G1 kernel sets
-    every one of them aside and its 512-entry list overflows (100 segments x 7 deferrals) -- k_acc_fixup
+    every one of them aside and its list overflows (segments of 8 entries x 7 deferrals each) -- k_acc_fixup
     raises `overflow` and the exact kernel behind it redoes the launch.  Deterministic, unlike a hot
     bucket of several points; covers the interleaved A|B1 pair launch (prove) and the single-query
     launches (L, H, msm_g1).  The G2 launch runs the exact kernel anyway.  Bytes == oracle."""
     import circom_compat_amd as cc
     rng = random.Random(812)
-    n = 800
+    # the list holds 512 entries in the emulator build, 2048 in the product (msm.h, MSM_FIX_CAP): 100 / 300
+    # segments of 8 entries defer 7 additions each
+    n = 800 if lib.path.endswith("libg16_emu.so") else 2400
     N = n + 1
     P = o.G1.mul(o.G1_GEN, 12345)
     Q = o.G2.mul(o.G2_GEN, 54321)
