@@ -448,8 +448,9 @@ def test_domain_2p26_on_one_gpu_not_refused(gpulib):
     """A domain the reference accepts (qap.rs:30-32,63-68: any n with a 2n-th root of unity, n <= 2^27)
     must not be refused: 2^26 constraints on ONE GPU -- past the size whose full point planes fit 288 GB,
     so plan_msm_configs (api.hip) picks planes < W for the witness queries.  Opt-in (G16_TEST_2P26=1:
-    ~35 GB of host memory for the key, several minutes; scripts/r4_chain26.sh runs it once per round and
-    keeps the log under profiles/): pairing check, wrong input rejected, and with
+    ~35 GB of host memory for the key, several minutes; the round's record is the bench line
+    profiles/r04_bench_chain26.json from scripts/r4_run1.sh, and scripts/r4_chain27.sh does the same at 2^27,
+    the reference's own limit): pairing check, wrong input rejected, and with
     G16_TEST_2P26_BYTES=1 the 256 bytes against the CPU restatement."""
     if not os.environ.get("G16_TEST_2P26"):
         pytest.skip("opt-in: G16_TEST_2P26=1")
