@@ -357,7 +357,8 @@ def test_capacity_point_2p25_on_one_gpu(gpulib):
         assert proof.raw == cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
 
 
-@pytest.mark.parametrize("kind,k", [("dense", 12), ("chain", 12), ("chain", 14), ("chain", 16), ("chain", 20)])
+@pytest.mark.parametrize("kind,k", [("dense", 12), ("chain", 12), ("chain", 14), ("chain", 16), ("chain", 20),
+                                    ("chain", 22)])     # 22: the headline key itself
 def test_key_generator_pinned_to_the_oracles_trapdoor_scalars(gpulib, kind, k):
     """Every large test proves under a key minted by the product's own g16_setup_create, and a
     self-consistent wrong key would still give GPU bytes == CPU bytes.  So the key generator is pinned
@@ -365,7 +366,7 @@ def test_key_generator_pinned_to_the_oracles_trapdoor_scalars(gpulib, kind, k):
     the A / B / C column sums, CircomReduction::h_query_scalars of qap.rs:90-105 -- field operations
     only) say that every query point is k_i * G; 1000 random indices per query (+ the ends) of the
     GPU-made A, B1, B2, L and H arrays are compared with k_i * G formed by the C restatement's plain
-    double-and-add (pinned to bn254_ref in tests/test_oracle.py).  At 2^16 / 2^20 the two big inverse
+    double-and-add (pinned to bn254_ref in tests/test_oracle.py).  At 2^16 / 2^20 / 2^22 the two big inverse
     transforms of the scalar side run on the C restatement's FFT (pinned likewise)."""
     import circom_compat_amd as cc
     import cpu_ref
