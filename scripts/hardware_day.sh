@@ -17,6 +17,11 @@ K=${1:-24}; STEPS=${2:-10}
 cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=gpurun_out/hardware_day; mkdir -p $O; export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 NDEV=$(python -c "import torch; print(torch.cuda.device_count())")
+# G16_HWDAY_FAKE=1: rehearsal of THIS SCRIPT on a one-GPU box -- every rank on device 0, gloo between the
+# processes (what tests/test_bench_shapes.py does): checks the script's own plumbing, measures nothing
+FAKE=${G16_HWDAY_FAKE:-0}
+if [ "$FAKE" = "1" ]; then NDEV=8; export G16_BENCH_BACKEND=gloo G16_BENCH_DEVICE=0; echo "REHEARSAL on one GPU: every number below is functional only"; fi
+export G16_HWDAY_FAKE=$FAKE
 echo "== 0. topology: $NDEV visible device(s)"
 rocm-smi --showtopo 2>/dev/null | tee $O/topo.txt | head -60
 if [ "$NDEV" -lt 2 ]; then echo "this box has one GPU: nothing to do here (tests/ and bench.py cover N = 1)"; exit 0; fi
@@ -36,13 +41,14 @@ w = cc.fr_from_ints(w_ints)
 single = cc.Prover(pk, mats)
 want = single.prove(rs[0], rs[1], w).raw
 single.close()
-ndev = torch.cuda.device_count()
+fake = os.environ.get("G16_HWDAY_FAKE") == "1"
+ndev = 8 if fake else torch.cuda.device_count()
 for n in (2, 4, 8):
     if n > ndev:
         break
     for shard in ("points", "buckets"):
         try:
-            pr = cc.Prover(pk, mats, devices=list(range(n)), shard=shard)   # runs the self-test; raises on a broken peer path
+            pr = cc.Prover(pk, mats, devices=[0] * n if fake else list(range(n)), shard=shard)   # runs the self-test; raises on a broken peer path
         except Exception as e:
             print(f"N={n} {shard}: CREATE FAILED: {e}")
             continue
