@@ -248,3 +248,16 @@ def test_python_sources_have_no_undefined_names():
                 bound.update(n.names)
         used = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
         assert not (used - bound), "%s: names used but never bound: %r" % (os.path.relpath(path, root), sorted(used - bound))
+
+
+def test_shell_scripts_parse():
+    """every scripts/*.sh at least parses (bash -n): the measurement scripts run once or twice per round on
+    a GPU box with a minute-scale turnaround, a syntax error there costs a whole call"""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "scripts", "*.sh")))
+    assert files
+    for f in files:
+        r = subprocess.run(["bash", "-n", f], capture_output=True, text=True)
+        assert r.returncode == 0, "%s: %s" % (os.path.basename(f), r.stderr)
