@@ -31,9 +31,12 @@ witness map distributed (four-step NTTs, two all-to-all exchanges), records gath
 Other workloads / modes (BASELINE configs 2 and 5, the reference's own bench circuit):
   --workload dense-skewed   3-term A rows / 2-term B rows, >= 50 % of the witness in {0, 1}, key
                             written and re-read through the snarkjs .zkey format (read_zkey path)
-  --workload poseidon       the shape of a circom Poseidon hash chain: x^5 S-boxes as three rows, 4-term
-                            linear combinations with full-width MDS / round constants on both the A
-                            and the B side, uniform 254-bit witness; key through the .zkey format
+  --workload poseidon       BASELINE configs[4]: a REAL Poseidon(2) hash chain, circomlib parameters (Grain LFSR,
+                            t = 3, R_F = 8, R_P = 57; pinned to circomlibjs' KATs by oracle/poseidon_ref.py),
+                            243 S-box rows per hash with the linear layers folded into rows of up to 61
+                            full-width terms (what circom --O2 leaves); R1CS not circom-compiled; key
+                            through the .zkey format
+  --workload poseidon-shaped  rounds 3-4's substitute: seeded constants, every lane materialised, 4-term rows
   --workload complex-circuit  tests/golden/complex-circuit-10000-10000.r1cs (benches/groth16.rs:87-108)
   --mode parts              witness map and each MSM timed separately (device-resident operands)
 
@@ -142,7 +145,7 @@ def dense_skewed_circuit(cc, k, seed=5, n_bits=4096, n_wide=64, p_bit=0.64):
     return mats, (A, B, Cm), w, n_vars
 
 
-def poseidon_circuit(cc, k, seed=7, t=3, full_rounds=8, partial_rounds=57):
+def poseidon_shaped_circuit(cc, k, seed=7, t=3, full_rounds=8, partial_rounds=57):
     """BASELINE configs[4] substitute with the SHAPE of a circom Poseidon hash chain (the real artefact
     needs circom + snarkjs + a ptau file: not generable offline): m = 2^k - 2 rows of chained width-3
     permutations, 8 full + 57 partial rounds, x^5 S-box.  As circom emits it without the sparse-matrix
@@ -234,6 +237,222 @@ def poseidon_circuit(cc, k, seed=7, t=3, full_rounds=8, partial_rounds=57):
     A = cc.Csr(a_rp, a_col, tab[np.asarray(a_cf, dtype=np.int64)])
     B = cc.Csr(b_rp, b_col, tab[np.asarray(b_cf, dtype=np.int64)])
     Cm = cc.Csr(c_rp, c_col, np.tile(tab[0], (len(c_col), 1)))
+    mats = cc.ConstraintMatrices(2, n_vars - 1, m, A, B)
+    return mats, (A, B, Cm), w, n_vars
+
+
+def poseidon_parameters(t=3, r_f=8, r_p=57, n_bits=254):
+    """circomlib's Poseidon parameter set for width t, generated the way the Poseidon paper's reference
+    script does (Grain LFSR in self-shrinking mode: round constants by rejection sampling, then the
+    Cauchy matrix 1 / (x_i + y_j) from the next 2t elements).  Workload data; the independent checker
+    is oracle/poseidon_ref.py, pinned to circomlibjs' hash KATs (tests/test_oracle.py compares both)."""
+    reg = int("01" + "0000" + format(n_bits, "012b") + format(t, "012b") + format(r_f, "010b")
+              + format(r_p, "010b") + "1" * 30, 2)             # bit 79 = the oldest bit b[0]
+    mask = (1 << 80) - 1
+
+    def clock():
+        nonlocal reg
+        b = ((reg >> 17) ^ (reg >> 28) ^ (reg >> 41) ^ (reg >> 56) ^ (reg >> 66) ^ (reg >> 79)) & 1
+        reg = ((reg << 1) | b) & mask
+        return b
+
+    for _ in range(160):
+        clock()
+
+    def field_bits():
+        v, got = 0, 0
+        while got < n_bits:
+            first, second = clock(), clock()
+            if first:
+                v, got = (v << 1) | second, got + 1
+        return v
+
+    rc = []
+    while len(rc) < (r_f + r_p) * t:
+        v = field_bits()
+        if v < R_MOD:
+            rc.append(v)
+    while True:
+        pts = [field_bits() % R_MOD for _ in range(2 * t)]
+        if len(set(pts)) == 2 * t and all((x + y) % R_MOD for x in pts[:t] for y in pts[t:]):
+            break
+    mds = [[pow((x + y) % R_MOD, R_MOD - 2, R_MOD) for y in pts[t:]] for x in pts[:t]]
+    return rc, mds
+
+
+def poseidon_chain_circuit(cc, k, n_hashes=None):
+    """BASELINE configs[4] as far as it can be built offline: a REAL Poseidon hash chain
+    h_{i+1} = Poseidon(2)([h_i, x_i]) over BN254 Fr with circomlib's parameters (t = 3, R_F = 8, R_P = 57,
+    x^5; `poseidon_parameters`), h_0 = 1, x_i = i + 2 -- so h_1 is circomlibjs' known answer
+    poseidon([1, 2]) = 0x115cc0f5...189a and the public output h_H is checked against the oracle's chain.
+
+    The R1CS is NOT circom-compiled (no circom / snarkjs offline).  It is what a linear-substitution
+    optimiser (circom --O2) leaves of the round function: ONLY the S-box rows -- 81 S-boxes x 3 rows
+    (x2 = in*in, x4 = x2*x2, x5 = x4*in: circomlib's Sigma template) = 243 rows per hash -- with every
+    linear layer (round constants, MDS products) folded into the linear combination that feeds the next
+    S-box.  The two lanes that skip the S-box in a partial round are never materialised, so the S-box
+    input of partial round r is a combination of ~r + 4 wires with full-width coefficients: A rows carry
+    up to 61 terms (9.3 per row on average), B rows 17.5 per row -- the width circomlib's Poseidon has
+    after --O2 (the sparse-matrix factorisation of circomlib changes the coefficients, not this growth).
+    The chain output is folded into the C side of the last S-box row (3 terms) as circom does for
+    `out <== lc`.  Wires: 0 = one, 1 = h_H (public), 2 = h_0, 3.. = x_i, then 243 wires per hash.
+
+    k = log2 of the domain: H = (2^k - 2) // 243 hashes unless n_hashes is given (m = 243 H rows)."""
+    R = R_MOD
+    t, r_f, r_p = 3, 8, 57
+    rounds = r_f + r_p
+    rc, M = poseidon_parameters(t, r_f, r_p)
+    H = n_hashes if n_hashes is not None else ((1 << k) - 2) // 243
+    assert H >= 1, "one Poseidon(2) permutation needs 243 rows: k >= 8"
+
+    # ---- one hash as a template over symbolic wires ('s', q) own S-box wires, ('p', j) the three
+    # last-round wires of the previous hash, ('h',) h_0, ('x',) the absorbed input, ('1',) the constant
+    def lc_scale_add(dst, src, c):
+        for key, v in src.items():
+            dst[key] = (dst.get(key, 0) + c * v) % R
+
+    def template(first):
+        h_in = {('h',): 1} if first else {('p', j): M[0][j] for j in range(t)}
+        lanes = [{}, h_in, {('x',): 1}]
+        rows = []                                    # (A lc, B lc, C wire)
+        q = 0
+        for r in range(rounds):
+            for i in range(t):
+                lanes[i] = dict(lanes[i])
+                lanes[i][('1',)] = (lanes[i].get(('1',), 0) + rc[r * t + i]) % R
+            full = r < r_f // 2 or r >= r_f // 2 + r_p
+            order = ([2, 1, 0] if r == rounds - 1 else [0, 1, 2]) if full else [0]
+            for i in order:
+                lc = {key: v for key, v in lanes[i].items() if v}
+                rows.append((lc, lc, ('s', q)))
+                rows.append(({('s', q): 1}, {('s', q): 1}, ('s', q + 1)))
+                rows.append(({('s', q + 1): 1}, lc, ('s', q + 2)))
+                lanes[i] = {('s', q + 2): 1}
+                q += 3
+            if r < rounds - 1:                       # the last mix is the consumer's business (('p', j) above)
+                mixed = []
+                for i in range(t):
+                    acc = {}
+                    for j in range(t):
+                        lc_scale_add(acc, lanes[j], M[i][j])
+                    mixed.append(acc)
+                lanes = mixed
+        assert q == 243 and len(rows) == 243
+        # last round ran lanes 2, 1, 0: wires s234..236 = lane 2, s237..239 = lane 1, s240..242 = lane 0
+        return rows
+
+    last_x5 = {0: 242, 1: 239, 2: 236}                # lane -> own wire index of its last-round x5
+    x_base = 3
+    s_base = 3 + H                                    # hash i owns wires s_base + 243 i + q
+
+    table, tindex = [1], {1: 0}
+
+    def cid(v):
+        if v not in tindex:
+            tindex[v] = len(table)
+            table.append(v)
+        return tindex[v]
+
+    def compile_rows(rows):
+        """rows -> per side (row_ptr, kind, off, coeff id): col = off + kind-specific base of hash i"""
+        sides = []
+        for side in (0, 1):
+            rp, kind, off, cf = [0], [], [], []
+            for row in rows:
+                for key, v in sorted(row[side].items(), key=lambda kv: (kv[0][0] != '1', kv[0])):
+                    kd = key[0]
+                    kind.append({'1': 0, 'h': 1, 'x': 2, 's': 3, 'p': 4}[kd])
+                    off.append(key[1] if kd == 's' else last_x5[key[1]] if kd == 'p' else 0)
+                    cf.append(cid(v))
+                rp.append(len(kind))
+            sides.append((np.asarray(rp, dtype=np.int64), np.asarray(kind, dtype=np.int64),
+                          np.asarray(off, dtype=np.int64), np.asarray(cf, dtype=np.int64)))
+        return sides
+
+    def tile(sides, hashes):
+        """CSR pieces of `sides` instantiated for the hash indices in `hashes`"""
+        out = []
+        hs = np.asarray(hashes, dtype=np.int64)
+        for rp, kind, off, cf in sides:
+            nnz = len(kind)
+            base = np.zeros((len(hs), 5), dtype=np.int64)
+            base[:, 1] = 2
+            base[:, 2] = x_base + hs
+            base[:, 3] = s_base + 243 * hs
+            base[:, 4] = s_base + 243 * (hs - 1)
+            col = off[None, :] + base[:, kind]
+            out.append((rp, col.reshape(-1), np.tile(cf, len(hs)), nnz))
+        return out
+
+    pieces = []
+    first_sides = compile_rows(template(True))
+    pieces.append((tile(first_sides, [0]), 1))
+    if H > 1:
+        gen_sides = compile_rows(template(False))
+        pieces.append((tile(gen_sides, list(range(1, H))), H - 1))
+
+    def assemble(side):
+        rps, cols, cfs, at = [np.zeros(1, dtype=np.int64)], [], [], 0
+        for tiles, count in pieces:
+            rp, col, cf, nnz = tiles[side]
+            per = rp[1:]
+            rps.append((at + (np.arange(count, dtype=np.int64) * nnz)[:, None] + per[None, :]).reshape(-1))
+            cols.append(col)
+            cfs.append(cf)
+            at += count * nnz
+        return np.concatenate(rps), np.concatenate(cols), np.concatenate(cfs)
+
+    a_rp, a_col, a_cf = assemble(0)
+    b_rp, b_col, b_cf = assemble(1)
+    m = 243 * H
+    out_own = s_base + 243 * (H - 1) + 242            # the wire the public output replaces
+    # C: row q of hash i defines wire s_base + 243 i + q; the very last row defines
+    # x5 = (out - M01 b - M02 c) / M00 with b, c the last-round x5 wires of lanes 1, 2
+    c_col = s_base + np.arange(m, dtype=np.int64)
+    inv00 = pow(M[0][0], R - 2, R)
+    c_cf = np.zeros(m, dtype=np.int64)
+    c_rp = np.arange(m + 1, dtype=np.int64)
+    lb = s_base + 243 * (H - 1) + last_x5[1]
+    lc_ = s_base + 243 * (H - 1) + last_x5[2]
+    c_col = np.concatenate([c_col[:m - 1], np.asarray([1, lb, lc_], dtype=np.int64)])
+    c_cf = np.concatenate([c_cf[:m - 1], np.asarray([cid(inv00), cid((R - M[0][1]) * inv00 % R),
+                                                      cid((R - M[0][2]) * inv00 % R)], dtype=np.int64)])
+    c_rp[m] = m + 2
+    n_vars = out_own                                  # wires 0 .. out_own - 1 (the last own wire is wire 1)
+    assert int(a_col.max()) < n_vars and int(b_col.max()) < n_vars
+
+    # ---- witness: the textbook permutation, wire by wire
+    w = [0] * n_vars
+    w[0], w[2] = 1, 1
+    h = 1
+    for i in range(H):
+        x = i + 2
+        w[x_base + i] = x
+        st = [0, h, x]
+        base = s_base + 243 * i
+        q = 0
+        for r in range(rounds):
+            st = [(st[j] + rc[r * t + j]) % R for j in range(t)]
+            full = r < r_f // 2 or r >= r_f // 2 + r_p
+            order = ([2, 1, 0] if r == rounds - 1 else [0, 1, 2]) if full else [0]
+            for j in order:
+                x2 = st[j] * st[j] % R
+                x4 = x2 * x2 % R
+                x5 = x4 * st[j] % R
+                if base + q + 2 < n_vars:
+                    w[base + q], w[base + q + 1], w[base + q + 2] = x2, x4, x5
+                else:
+                    w[base + q], w[base + q + 1] = x2, x4
+                st[j] = x5
+                q += 3
+            st = [(M[j][0] * st[0] + M[j][1] * st[1] + M[j][2] * st[2]) % R for j in range(t)]
+        h = st[0]
+    w[1] = h
+    tab = cc.fr_from_ints(table)
+    u32 = lambda a: np.ascontiguousarray(a, dtype=np.uint32)
+    A = cc.Csr(u32(a_rp), u32(a_col), tab[a_cf])
+    B = cc.Csr(u32(b_rp), u32(b_col), tab[b_cf])
+    Cm = cc.Csr(u32(c_rp), u32(c_col), tab[c_cf])
     mats = cc.ConstraintMatrices(2, n_vars - 1, m, A, B)
     return mats, (A, B, Cm), w, n_vars
 
@@ -370,7 +589,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2", type=int, default=22, help="log2 of the domain (m = 2^k - 2 constraints)")
-    ap.add_argument("--workload", choices=["chain", "dense-skewed", "poseidon", "complex-circuit"], default="chain")
+    ap.add_argument("--workload", choices=["chain", "dense-skewed", "poseidon", "poseidon-shaped", "complex-circuit"], default="chain")
     ap.add_argument("--mode", choices=["prove", "parts"], default="prove")
     ap.add_argument("--cpu-log2", type=int, default=17, help="probe size of the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-own", action="store_true",
@@ -441,7 +660,15 @@ def main():
                 f"2-term B rows), 2^{k}-2 constraints, skewed witness, "
                 "key through the snarkjs .zkey writer + read_zkey")
     elif args.workload == "poseidon":
-        mats, (A, B, Cm), w_ints, n_vars = poseidon_circuit(cc, k)
+        mats, (A, B, Cm), w_ints, n_vars = poseidon_chain_circuit(cc, k)
+        desc = (f"Poseidon(2) hash chain (circomlib parameters: Grain-LFSR constants + Cauchy MDS, t = 3, R_F = 8, "
+                f"R_P = 57; KAT-pinned: h_1 = circomlibjs poseidon([1, 2])), R1CS NOT circom-compiled (no circom / snarkjs / "
+                f"ptau offline): {mats.num_constraints // 243} hashes x 243 S-box rows = {mats.num_constraints} "
+                f"constraints in the 2^{k} domain, {n_vars} wires, linear layers folded into rows of up to 61 "
+                f"full-width terms ({len(A.col) / mats.num_constraints:.1f} / {len(B.col) / mats.num_constraints:.1f} nnz per "
+                "A / B row), key through the snarkjs .zkey writer + read_zkey (Coefs path)")
+    elif args.workload == "poseidon-shaped":
+        mats, (A, B, Cm), w_ints, n_vars = poseidon_shaped_circuit(cc, k)
         desc = (f"SYNTHETIC Poseidon-shaped SUBSTITUTE for BASELINE configs[4] (NOT circom-generated: seeded constants, "
                 f"no circom / snarkjs / ptau offline): hash-chain R1CS (width 3, 8 + 57 rounds, x^5 as 3 rows, 4-term linear "
                 f"combinations with full-width MDS / round constants, uniform witness), 2^{k}-2 constraints, "

@@ -642,7 +642,7 @@ def _through_zkey(cc, tmp_path, name, A, B, Cm, n_vars, mats0, seed):
 def test_poseidon_shaped_2p20_through_zkey_vs_cpu_restatement(gpulib, tmp_path):
     """BASELINE configs[4] substitute with the shape of a circom Poseidon hash chain AT SIZE (2^20 rows:
     x^5 S-boxes as three rows, 4-term linear combinations with full-width MDS / round constants in A
-    AND B, uniform 254-bit witness -- bench.poseidon_circuit): satisfiable (GPU constraint check), key
+    AND B, uniform 254-bit witness -- bench.poseidon_shaped_circuit): satisfiable (GPU constraint check), key
     through g16_zkey_write -> read_zkey (the Coefs path, src/zkey.rs:151-196, with full-width values),
     proof bytes == the CPU restatement's, pairing accepted, wrong public input rejected."""
     import circom_compat_amd as cc
@@ -650,7 +650,7 @@ def test_poseidon_shaped_2p20_through_zkey_vs_cpu_restatement(gpulib, tmp_path):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     import bench
     k = 20
-    mats0, (A, B, Cm), w_ints, n_vars = bench.poseidon_circuit(cc, k)
+    mats0, (A, B, Cm), w_ints, n_vars = bench.poseidon_shaped_circuit(cc, k)
     assert sum(1 for x in w_ints if x in (0, 1)) <= 4           # uniform witness
     wide = sum(1 for x in cc.fr_to_ints(A.coeff[:20000]) if x.bit_length() > 200)
     assert wide > 10000                                          # full-width coefficients dominate
@@ -666,20 +666,60 @@ def test_poseidon_shaped_2p20_through_zkey_vs_cpu_restatement(gpulib, tmp_path):
     assert not o.verify_proof(_vk_dict(pk), [(w_ints[1] + 1) % o.R_MOD], H.proof_from_bytes(proof.raw))
 
 
+def test_real_poseidon_chain_2p20_through_zkey_one_gpu_and_8_ranks(gpulib, tmp_path):
+    """BASELINE configs[4] as far as it can be built offline: a REAL Poseidon(2) hash chain with
+    circomlib's Grain-LFSR parameters (bench.poseidon_chain_circuit; the checker oracle/poseidon_ref.py is
+    pinned to circomlibjs' KATs) AT SIZE: 4315 hashes = 1 048 545 rows, 1 052 862 wires (more wires than
+    the 2^20 domain), 9.7 M / 18.4 M full-width coefficients in A / B (rows of up to 61 terms).  The
+    public output is the oracle chain's h_4315 and wire values include circomlibjs' poseidon([1, 2]);
+    satisfiable (GPU constraint check); key through g16_zkey_write -> read_zkey (the Coefs path,
+    src/zkey.rs:151-196); proof bytes == the CPU restatement's on ONE GPU and on 8 emulated ranks under
+    BOTH cuts; pairing accepted for h_H, rejected for h_H + 1."""
+    import circom_compat_amd as cc
+    import cpu_ref
+    import poseidon_ref
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    k = 20
+    mats0, (A, B, Cm), w_ints, n_vars = bench.poseidon_chain_circuit(cc, k)
+    n_hashes = mats0.num_constraints // 243
+    assert n_hashes == 4315 and n_vars > (1 << k) and int(np.diff(A.row_ptr).max()) == 61
+    chain = poseidon_ref.hash_chain(1, [i + 2 for i in range(n_hashes)])
+    assert chain[1] == poseidon_ref.KATS[(1, 2)] and w_ints[1] == chain[-1]
+    circ = cc.CircomCircuit(type("R", (), dict(a=A, b=B, c=Cm, num_constraints=mats0.num_constraints,
+                                               wire_mapping=None, num_inputs=2, num_variables=n_vars)), w_ints)
+    assert circ.first_unsatisfied() == -1
+    pk, mats, rng = _through_zkey(cc, tmp_path, "poseidon_real20.zkey", A, B, Cm, n_vars, mats0, k)
+    assert np.array_equal(mats.b.col, B.col) and np.array_equal(mats.a.coeff, A.coeff)
+    rs = cc.fr_from_ints([rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)])
+    w = cc.fr_from_ints(w_ints)
+    want = cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
+    proof = cc.Prover(pk, mats).prove(rs[0], rs[1], w)
+    assert proof.raw == want
+    assert o.verify_proof(_vk_dict(pk), [chain[-1]], H.proof_from_bytes(proof.raw))
+    assert not o.verify_proof(_vk_dict(pk), [(chain[-1] + 1) % o.R_MOD], H.proof_from_bytes(proof.raw))
+    for shard in ("points", "buckets"):
+        pr = cc.Prover(pk, mats, devices=[0] * 8, shard=shard)
+        assert pr.info()["shard_mode"] == shard
+        assert pr.prove(rs[0], rs[1], w).raw == want, shard
+        pr.close()
+
+
 @pytest.mark.parametrize("shard", ["points", "buckets"])
-@pytest.mark.parametrize("workload", ["dense-skewed", "poseidon"])
+@pytest.mark.parametrize("workload", ["dense-skewed", "poseidon-shaped", "poseidon"])
 def test_config5_substitutes_sharded_over_8_ranks_2p17(gpulib, tmp_path, workload, shard):
     """The two config-5 substitutes through g16_ctx_create_multi([0] * 8) at 2^17 rows, both ways of
     cutting the MSMs: `dense-skewed` puts ~45 % of all sort entries into ONE bucket (the value-1 wires)
     -- split over point-range shards it spans many lanes of every rank, under bucket ranges it makes
-    one partition larger than a rank's fair share (that rank owns it alone); `poseidon` is the
-    uniform full-width corner.  bytes == the CPU restatement's, two proofs."""
+    one partition larger than a rank's fair share (that rank owns it alone); `poseidon-shaped` is the
+    uniform full-width corner with narrow rows, `poseidon` the real hash chain (rows of up to 61 terms).  bytes == the CPU restatement's, two proofs."""
     import circom_compat_amd as cc
     import cpu_ref
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     import bench
     k = 17
-    gen = bench.dense_skewed_circuit if workload == "dense-skewed" else bench.poseidon_circuit
+    gen = {"dense-skewed": bench.dense_skewed_circuit, "poseidon-shaped": bench.poseidon_shaped_circuit,
+           "poseidon": bench.poseidon_chain_circuit}[workload]
     mats0, (A, B, Cm), w_ints, n_vars = gen(cc, k)
     pk, mats, rng = _through_zkey(cc, tmp_path, workload + "17.zkey", A, B, Cm, n_vars, mats0, k)
     w = cc.fr_from_ints(w_ints)

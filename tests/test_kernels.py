@@ -769,7 +769,7 @@ def test_bucket_range_sharding_windows_planes_and_skew(lib, logm, world, wb, pla
 
 
 def test_poseidon_shaped_generator_full_width_rows_vs_oracle(lib):
-    """bench.poseidon_circuit (the config-5 substitute with full-width coefficients on both sides of
+    """bench.poseidon_shaped_circuit (the config-5 substitute with full-width coefficients on both sides of
     the product rows) at 2^7 rows: satisfiable, and the proof over a trapdoor key == the Python oracle's
     -- on one device and on 4 bucket-sharded ranks."""
     import sys
@@ -779,7 +779,7 @@ def test_poseidon_shaped_generator_full_width_rows_vs_oracle(lib):
     from circom_compat_amd import _binding
     saved, _binding._default = _binding._default, lib       # the generator converts through the default library
     try:
-        mats, (A, B, Cm), w, n_vars = bench.poseidon_circuit(cc, 7)
+        mats, (A, B, Cm), w, n_vars = bench.poseidon_shaped_circuit(cc, 7)
     finally:
         _binding._default = saved
     circ = cc.CircomCircuit(type("R", (), dict(a=A, b=B, c=Cm, num_constraints=mats.num_constraints,
@@ -802,6 +802,50 @@ def test_poseidon_shaped_generator_full_width_rows_vs_oracle(lib):
     pr = cc.Prover(pk, mats, lib=lib, devices=[0] * 4, shard="buckets")
     assert pr.prove(r, s, w).raw == want
     pr.close()
+
+
+def test_poseidon_chain_one_hash_public_output_is_the_circomlibjs_kat(lib):
+    """bench.poseidon_chain_circuit (BASELINE configs[4]: a REAL Poseidon(2) instance with circomlib's
+    Grain-LFSR parameters) at one hash = 243 rows: the circuit is satisfiable, its PUBLIC output is
+    circomlibjs' known answer poseidon([1, 2]) = 0x115cc0f5...189a, rows carry up to 61 full-width terms,
+    and the proof over a trapdoor key == the Python oracle's -- on one device and on 4 bucket-sharded
+    ranks; the oracle's pairing check accepts it for the KAT and rejects it for KAT + 1."""
+    import sys
+    import circom_compat_amd as cc
+    import poseidon_ref
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from circom_compat_amd import _binding
+    saved, _binding._default = _binding._default, lib       # the generator converts through the default library
+    try:
+        mats, (A, B, Cm), w, n_vars = bench.poseidon_chain_circuit(cc, 8)
+    finally:
+        _binding._default = saved
+    kat = 0x115cc0f5e7d690413df64c6b9662e9cf2a3617f2743245519e19607a4417189a
+    assert mats.num_constraints == 243 and w[1] == kat == poseidon_ref.poseidon([1, 2])
+    circ = cc.CircomCircuit(type("R", (), dict(a=A, b=B, c=Cm, num_constraints=mats.num_constraints,
+                                               wire_mapping=None, num_inputs=2, num_variables=n_vars)), w)
+    assert circ.first_unsatisfied(lib) == -1
+
+    def rows(m):
+        cf = cc.fr_to_ints(m.coeff, lib)
+        return [[(int(m.col[j]), cf[j]) for j in range(m.row_ptr[i], m.row_ptr[i + 1])] for i in range(m.num_rows)]
+    cons = list(zip(rows(A), rows(B), rows(Cm)))
+    assert max(len(a) for a, _b, _c in cons) == 61 and len(cons[-1][2]) == 3
+    rng = random.Random(78)
+    opk = o.trapdoor_setup(cons, n_vars, 1, *[rng.randrange(1, o.R_MOD) for _ in range(5)])
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+    want = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2,
+                                                                       len(cons), w))
+    pk = H.pk_from_oracle(opk)
+    proof = cc.Prover(pk, mats, lib=lib).prove(r, s, w)
+    assert proof.raw == want
+    pr = cc.Prover(pk, mats, lib=lib, devices=[0] * 4, shard="buckets")
+    assert pr.prove(r, s, w).raw == want
+    pr.close()
+    assert o.verify_proof(opk, [kat], H.proof_from_bytes(proof.raw))
+    assert not o.verify_proof(opk, [kat + 1], H.proof_from_bytes(proof.raw))
 
 
 def test_sibling_ctx_shares_planes_two_proofs_in_flight(lib, golden):
@@ -853,3 +897,38 @@ def test_sibling_ctx_shares_planes_two_proofs_in_flight(lib, golden):
         cc.Prover(pk, mats, lib=lib, sibling_of=multi)
     multi.close()
     donor.close()
+
+
+@pytest.mark.parametrize("n_rows", [10, 29])
+def test_more_wires_than_the_domain(lib, n_rows):
+    """A circuit whose wire count exceeds its evaluation domain (every row brings four fresh wires:
+    n_vars = 4 m + 2 > 2^ceil(log2(m + 2))): the A / B1 / B2 / L queries are longer than the H query and
+    than the NTT size -- what the real Poseidon chain of configs[4] has at 2^20 (1 052 862 wires, domain
+    2^20).  Proof bytes == the Python oracle's on one device and on 4 ranks, both cuts."""
+    import circom_compat_amd as cc
+    rng = random.Random(1000 + n_rows)
+    P = o.R_MOD
+    w = [1, 0]
+    cons = []
+    for i in range(n_rows):
+        a, b, c = (rng.randrange(P) for _ in range(3))
+        base = len(w)
+        w.extend([a, b, c, (a + 5 * b) * c % P])
+        cons.append(([(base, 1), (base + 1, 5)], [(base + 2, 1)], [(base + 3, 1)]))
+    cons.append(([(len(w) - 1, 1)], [(0, 1)], [(1, 1)]))
+    w[1] = w[-1]
+    n_vars = len(w)
+    dom = 1 << (len(cons) + 2 - 1).bit_length()
+    assert n_vars > 2 * dom
+    opk = o.trapdoor_setup(cons, n_vars, 1, *[rng.randrange(1, P) for _ in range(5)])
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, lib)
+    pk = H.pk_from_oracle(opk)
+    r, s = rng.randrange(P), rng.randrange(P)
+    want = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2,
+                                                                       len(cons), w))
+    assert cc.Prover(pk, mats, lib=lib).prove(r, s, w).raw == want
+    for shard in ("points", "buckets"):
+        pr = cc.Prover(pk, mats, lib=lib, devices=[0] * 4, shard=shard)
+        assert pr.prove(r, s, w).raw == want
+        pr.close()

@@ -314,3 +314,45 @@ def test_c_oracle_prove_matches_python_oracle_2p12_2p14(logm):
     assert H.fr_from_mont_arr(h) == o.witness_map_from_matrices(ar, br, ni, len(cons), wit)
     want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=ar, b=br), ni, len(cons), wit)
     assert got == o.proof_to_bytes(want)
+
+
+def test_poseidon_reference_matches_circomlibjs_kats(emu):
+    """BASELINE configs[4] checker: oracle/poseidon_ref.py (Grain-LFSR parameters of the Poseidon paper's
+    reference generator, circomlib's t / R_F / R_P) reproduces circomlibjs' hash known answers with no
+    constant typed in; bench.py's own generator (an independent implementation of the same LFSR) yields
+    the same 195 round constants and 3 x 3 MDS matrix; the witness of bench.poseidon_chain_circuit walks
+    the oracle's hash chain (h_1 = the KAT, public output = h_H) and satisfies every row (the
+    satisfiability kernel on the emulator)."""
+    import sys
+    import poseidon_ref as pr
+    import circom_compat_amd as cc
+    from circom_compat_amd import _binding
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert pr.poseidon([1, 2]) == 0x115cc0f5e7d690413df64c6b9662e9cf2a3617f2743245519e19607a4417189a == pr.KATS[(1, 2)]
+    assert pr.poseidon([1]) == 18586133768512220936620570745912940619677854269274689475585506675881198879027
+    rc, mds = pr.parameters(3)
+    assert len(rc) == 65 * 3 and all(0 < c < o.R_MOD for c in rc)
+    assert bench.poseidon_parameters(3, 8, 57) == (rc, mds)
+    assert bench.poseidon_parameters(2, 8, 56) == pr.parameters(2)
+    saved, _binding._default = _binding._default, emu
+    try:
+        mats, (A, B, Cm), w, n_vars = bench.poseidon_chain_circuit(cc, 11)
+    finally:
+        _binding._default = saved
+    n_hashes = mats.num_constraints // 243
+    assert n_hashes == 8 and mats.num_constraints == 243 * 8
+    chain = pr.hash_chain(1, [i + 2 for i in range(n_hashes)])
+    assert chain[1] == pr.KATS[(1, 2)] and w[1] == chain[-1] and w[2] == 1 and w[3:3 + n_hashes] == list(range(2, 10))
+    # the x5 wire of lane 0's last S-box of hash 0 and the two beside it mix into h_1
+    s_base = 3 + n_hashes
+    x5 = [w[s_base + q] for q in (242, 239, 236)]
+    assert sum(m * x for m, x in zip(mds[0], x5)) % o.R_MOD == chain[1]
+    circ = cc.CircomCircuit(type("R", (), dict(a=A, b=B, c=Cm, num_constraints=mats.num_constraints,
+                                               wire_mapping=None, num_inputs=2, num_variables=n_vars)), w)
+    assert circ.first_unsatisfied(emu) == -1
+    bad = list(w)
+    bad[s_base + 700] ^= 1
+    circ_bad = cc.CircomCircuit(type("R", (), dict(a=A, b=B, c=Cm, num_constraints=mats.num_constraints,
+                                                   wire_mapping=None, num_inputs=2, num_variables=n_vars)), bad)
+    assert circ_bad.first_unsatisfied(emu) >= 0
