@@ -537,6 +537,147 @@ def complex_circuit(cc):
 
 
 # ------------------------------------------------------------------------------------------------
+def measure_pmc_traffic(args, k, budget_s=150.0):
+    """roofline.traffic measured BY THIS RUN: bench.py re-executes itself for two
+    proofs under `rocprofv3 --pmc` -- one pass for the L2's read requests to HBM by size, one for its
+    write requests (separate passes and no trace domain, as MI355X_MICROARCH.md prescribes; sized by
+    the TCC_EA0_*REQ_{32,64,128}B counters, which sidesteps the FETCH_SIZE x 2 correction of gfx950) --
+    and parses the per-dispatch counters of the accumulation kernels (scripts/pmc_traffic.py).  Returns
+    (record or None, note)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 is not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import pmc_traffic
+    out = tempfile.mkdtemp(prefix="g16_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", G16_NO_OVERLAP="1", G16_BENCH_NO_PIPELINE="1")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--no-pmc", "--log2", str(k), "--steps", "2",
+             "--warmup", "0", "--cpu-log2", "0", "--workload", args.workload, "--window-bits", str(args.window_bits),
+             "--planes", str(args.planes)]
+    t0 = time.time()
+    groups = ["TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B", "TCC_EA0_WRREQ TCC_EA0_WRREQ_64B"]
+    try:
+        for i, grp in enumerate(groups):
+            left = budget_s - (time.time() - t0)
+            if left < 20:
+                return None, f"PMC passes stopped after {time.time() - t0:.0f} s (budget {budget_s:.0f} s)"
+            cmd = (["rocprofv3", "--pmc"] + grp.split() + ["--kernel-include-regex", "k_bucket_accumulate", "-f", "csv",
+                                                         "-d", os.path.join(out, f"p{i}"), "-o", f"p{i}", "--"] + child)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc pass {i} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+        rec = pmc_traffic.collect(out, k)
+        if not rec.get("launches_averaged"):
+            return None, "the PMC passes produced no counter rows for k_bucket_accumulate"
+        rec["passes_s"] = round(time.time() - t0, 1)
+        return rec, (f"THIS RUN: two rocprofv3 --pmc passes of `bench.py --steps 2` ({rec['passes_s']} s) after the timed "
+                     f"region; read requests sized by TCC_EA0_RDREQ_32B/_64B/_128B, writes by TCC_EA0_WRREQ[_64B]; "
+                     f"{rec['launches_averaged']} single-query launches averaged")
+    except subprocess.TimeoutExpired:
+        return None, f"PMC passes timed out (budget {budget_s:.0f} s)"
+    except Exception as e:  # noqa: BLE001 -- the traffic figure is an extra: fall back to the stamped record
+        return None, f"PMC passes failed: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+# ------------------------------------------------------------------------------------------------
+class ClockSampler:
+    """sclk / package power of one GPU sampled on a host thread while proofs run (a slow box
+    must be visible in the record).  sysfs hwmon (freq1_input in Hz, power1_average / power1_input in
+    microwatts: one read each, ~20 us) when the box exposes it, `rocm-smi --showclocks --showpower
+    --json` (~0.3 s per sample) otherwise.  mark(label) starts a new labelled interval."""
+
+    def __init__(self, ordinal, period=0.004):
+        import glob
+        import threading
+        self.samples, self.label, self.source = [], "warmup", None
+        self._stop = threading.Event()
+        self._th = None
+        if ordinal is None:
+            return
+        cards = []
+        for c in sorted(glob.glob("/sys/class/drm/card[0-9]*"), key=lambda x: int(x.rsplit("card", 1)[1])):
+            try:
+                if open(os.path.join(c, "device", "vendor")).read().strip() != "0x1002":
+                    continue
+            except OSError:
+                continue
+            hw = sorted(glob.glob(os.path.join(c, "device", "hwmon", "hwmon*")))
+            if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+                cards.append(hw[0])
+        self._freq = self._pow = None
+        if ordinal < len(cards):
+            self._freq = os.path.join(cards[ordinal], "freq1_input")
+            for name in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(cards[ordinal], name)):
+                    self._pow = os.path.join(cards[ordinal], name)
+                    break
+            self.source = f"sysfs {self._freq}" + (f" + {os.path.basename(self._pow)}" if self._pow else "")
+        else:
+            import shutil
+            if not shutil.which("rocm-smi"):
+                return
+            self._ordinal, period = ordinal, 0.05
+            self.source = "rocm-smi --showclocks --showpower --json"
+        self._period = period
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+
+    def _read(self):
+        if self._freq:
+            try:
+                f = int(open(self._freq).read()) / 1e6
+                pw = int(open(self._pow).read()) / 1e6 if self._pow else None
+                return f, pw
+            except (OSError, ValueError):
+                return None
+        import subprocess
+        try:
+            r = subprocess.run(["rocm-smi", "-d", str(self._ordinal), "--showclocks", "--showpower", "--json"],
+                               capture_output=True, text=True, timeout=5)
+            card = next(iter(json.loads(r.stdout).values()))
+            f = pw = None
+            for key, v in card.items():
+                if key.startswith("sclk clock speed"):
+                    f = float(str(v).strip("()Mhz "))
+                elif "Power (W)" in key and pw is None:
+                    pw = float(v)
+            return (f, pw) if f else None
+        except Exception:  # noqa: BLE001 -- a sampler never fails the bench
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            x = self._read()
+            if x:
+                self.samples.append((self.label, x[0], x[1]))
+            self._stop.wait(self._period)
+
+    def mark(self, label):
+        self.label = label
+
+    def stop(self):
+        self._stop.set()
+        if self._th:
+            self._th.join(timeout=6)
+            self._th = None
+
+    def summary(self):
+        def med(v):
+            v = sorted(v)
+            return v[len(v) // 2] if v else None
+        out = {"source": self.source}
+        for label in ("timed", "after"):
+            fs = [f for l_, f, _ in self.samples if l_ == label]
+            ps = [pw for l_, _, pw in self.samples if l_ == label and pw is not None]
+            out[label] = {"samples": len(fs), "sclk_mhz_median": med(fs), "sclk_mhz_min": min(fs) if fs else None,
+                          "sclk_mhz_max": max(fs) if fs else None, "power_w_median": med(ps)}
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
 def setup_prover(cc, torch, args, mode, rank, local_rank, n_gpus, world, one_gpu, A, B, Cm, n_vars, tox,
                  mats, w, rs, w_ints):
     """Key + ctx + resident witness for one launch mode.  Returns (active, pk, mats, m, prover, w_dev,
@@ -601,6 +742,9 @@ def main():
     ap.add_argument("--planes", type=int, default=0)
     ap.add_argument("--shard", choices=["auto", "points", "buckets"], default="auto",
                     help="N > 1: MSMs cut by point range or by bucket range (auto = points)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (N = 1, default workload)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
@@ -686,20 +830,30 @@ def main():
     rs = cc.fr_from_ints([r, s])
     w = cc.fr_from_ints(w_ints)
 
-    # Under torch.distributed.run the in-library ctx is tried first (rank 0 drives every device); if
-    # it cannot be built or its first proof does not verify, every rank falls back to its own ctx
-    # with RCCL collectives in between -- the line then says so (config.parallelism, fallback_reason).
+    # Under torch.distributed.run BOTH N > 1 paths are timed by default (round 5): first the in-library
+    # ctx (rank 0 drives every device: peer copies over xGMI, no collective library), then one ctx per
+    # process with RCCL all_to_all / all_gather in between -- north_star's wording -- on the same key,
+    # witness and (r, s); `value` is the faster, `value_inlib` / `value_rccl` / `rccl_ranks` say which
+    # ran how.  If the in-library ctx cannot be built or its first proof does not verify, only the
+    # per-process path is timed and the line says so (config.parallelism, fallback_reason).
     pg_nccl = mode == "ranks" and backend == "nccl"   # the default process group lives on the GPUs
-    grp = None                                        # RCCL group of the fallback (default group: gloo)
-    fallback_reason = None
-    while True:
+    both = world > 1 and mode == "inlib" and not os.environ.get("G16_BENCH_MODE")
+    st = {"grp": None, "fallback_reason": None, "rccl_ranks": 0}
+
+    def barrier():
+        if dist:
+            dist.barrier()
+
+    def measure(mode):
+        """ctx + resident witness for one launch mode, W untimed proofs, EXACTLY K timed proofs between
+        barrier + synchronize on both sides, max over ranks."""
         trial = mode == "inlib" and world > 1
         try:
-            (active, pk_, mats_, m_, prover, w_dev, w_ptr, zkey_path) = setup_prover(
+            (active, pk_, mats_, m_, prover, w_dev, w_ptr, zk) = setup_prover(
                 cc, torch, args, mode, rank, local_rank, n_gpus, world, one_gpu, A, B, Cm, n_vars, tox,
                 mats, w, rs, w_ints)
             ok, why = True, ""
-        except Exception as e:  # noqa: BLE001 -- anything the trial throws selects the fallback
+        except Exception as e:  # noqa: BLE001 -- anything the trial throws selects the per-process path
             if not trial:
                 raise
             ok, why = False, f"{type(e).__name__}: {e}"
@@ -709,103 +863,151 @@ def main():
             ok, why = flag
             if not ok:
                 if rank == 0:
-                    print(f"bench.py: in-library multi-device ctx failed ({why}); falling back to one "
-                          "ctx per process with RCCL collectives", file=sys.stderr)
-                fallback_reason, mode = why, "ranks"
+                    print(f"bench.py: in-library multi-device ctx failed ({why}); only the per-process path "
+                          "(RCCL collectives) is timed", file=sys.stderr)
+                st["fallback_reason"] = why
                 import gc
                 gc.collect()                      # a half-built in-library ctx frees its HBM here
-                if backend == "nccl":
-                    torch.cuda.set_device(local_rank)
-                    grp = dist.new_group(backend="nccl")
-                continue
-        break
-    if pk_ is not None:
-        pk, mats, m = pk_, mats_, m_
-    dev = f"cuda:{torch.cuda.current_device()}" if active else "cpu"
-    if active:
-        torch.cuda.synchronize()
-    t_setup = time.time() - t_setup
+                return None
+        dev = f"cuda:{torch.cuda.current_device()}" if active else "cpu"
+        if active:
+            torch.cuda.synchronize()
 
-    # ---- per-rank path: RCCL collectives on a torch stream the library orders itself against
-    if mode == "ranks":
-        xs = torch.cuda.Stream(priority=-1)   # high priority: shares a hardware queue with the aux stream, not with the MSM streams
-        prover.set_exchange_stream(xs.cuda_stream)
-        dist_wm = prover.dist_wm
-        if dist_wm:
+        # ---- per-rank path: RCCL collectives on a torch stream the library orders itself against
+        if mode == "ranks":
+            grp = st["grp"]
+            xs = torch.cuda.Stream(priority=-1)   # high priority: shares a hardware queue with the aux stream, not with the MSM streams
+            prover.set_exchange_stream(xs.cuda_stream)
+            if not prover.dist_wm:
+                raise SystemExit("mode 'ranks' runs the fully sharded prover (G16_BENCH_DIST_WM=1)")
             nbytes = prover.exchange_bytes()
             send = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             recv = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        part_t = cc.device_tensor(prover.partial_buffer(), 1024, dev)
-        gath_t = cc.device_tensor(prover.gather_buffer(), world * 1024, dev)
+            part_t = cc.device_tensor(prover.partial_buffer(), 1024, dev)
+            gath_t = cc.device_tensor(prover.gather_buffer(), world * 1024, dev)
+            if backend == "nccl":
+                st["rccl_ranks"] = dist.get_world_size(grp)
 
-        # (round 4: these two definitions had been deleted by mistake in round 3 together with the h
-        # all-gather -- the per-process path, i.e. G16_BENCH_MODE=ranks AND the fallback behind a failed
-        # in-library ctx, died with a NameError; scripts/r4_nshape.sh now runs both shapes every round)
-        def exchange():
-            with torch.cuda.stream(xs):
-                if backend == "nccl":
-                    dist.all_to_all_single(recv, send, group=grp)
-                else:
-                    xs.synchronize()
-                    hs, hr = send.cpu(), torch.empty(nbytes, dtype=torch.uint8)
-                    dist.all_to_all_single(hr, hs)
-                    recv.copy_(hr)
+            def exchange():
+                with torch.cuda.stream(xs):
+                    if backend == "nccl":
+                        dist.all_to_all_single(recv, send, group=grp)
+                    else:
+                        xs.synchronize()
+                        hs, hr = send.cpu(), torch.empty(nbytes, dtype=torch.uint8)
+                        dist.all_to_all_single(hr, hs)
+                        recv.copy_(hr)
 
-        def gather():
-            with torch.cuda.stream(xs):
-                if backend == "nccl":
-                    dist.all_gather_into_tensor(gath_t, part_t, group=grp)
-                else:
-                    xs.synchronize()
-                    parts = [torch.empty(1024, dtype=torch.uint8) for _ in range(world)]
-                    dist.all_gather(parts, part_t.cpu())
-                    gath_t.copy_(torch.cat(parts))
+            def gather():
+                with torch.cuda.stream(xs):
+                    if backend == "nccl":
+                        dist.all_gather_into_tensor(gath_t, part_t, group=grp)
+                    else:
+                        xs.synchronize()
+                        parts = [torch.empty(1024, dtype=torch.uint8) for _ in range(world)]
+                        dist.all_gather(parts, part_t.cpu())
+                        gath_t.copy_(torch.cat(parts))
 
-    def step():
-        if mode in ("single", "inlib"):
-            return prover.prove_dev(rs[0], rs[1], w_ptr)
-        if dist_wm:
+        def step():
+            if mode in ("single", "inlib"):
+                return prover.prove_dev(rs[0], rs[1], w_ptr)
             prover.dist_phase1(rs[0], rs[1], w_ptr, send.data_ptr())
             exchange()
             prover.dist_phase2(recv.data_ptr(), send.data_ptr())
             exchange()
             prover.dist_phase3_dev(recv.data_ptr())
-        else:
-            raise SystemExit("mode 'ranks' runs the fully sharded prover (G16_BENCH_DIST_WM=1)")
-        gather()
-        return prover.prove_finish_dev(rs[0], rs[1])
+            gather()
+            return prover.prove_finish_dev(rs[0], rs[1])
 
-    def barrier():
+        proof = None
+        for _ in range(args.warmup):
+            if active:
+                proof = step()
+        if active:
+            prover.set_profiling(True)
+        sampler = ClockSampler(local_rank if active else None) if rank == 0 else None
+        barrier()
+        if active:
+            torch.cuda.synchronize()
+        if sampler:
+            sampler.mark("timed")
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if active:
+                proof = step()
+        if active:
+            torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if sampler:
+            sampler.mark("after")
         if dist:
-            dist.barrier()
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if pg_nccl else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return dict(mode=mode, elapsed=elapsed, proof=proof, prover=prover, active=active, pk=pk_, mats=mats_,
+                    m=m_, w_dev=w_dev, w_ptr=w_ptr, zkey=zk, dev=dev, step=step, sampler=sampler)
 
-    proof = None
-    for _ in range(args.warmup):
-        if active:
-            proof = step()
-    if active:
-        prover.set_profiling(True)
-    barrier()
-    if active:
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if active:
-            proof = step()
-    if active:
-        torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=dev if pg_nccl else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def release(res):
+        if res and res["active"]:
+            if res["sampler"]:
+                res["sampler"].stop()
+            res["prover"].set_profiling(False)
+            res["prover"].close()
+            res["prover"] = None
+            if res["zkey"] and os.path.exists(res["zkey"]):
+                os.remove(res["zkey"])
+            import gc
+            gc.collect()
+
+    def rccl_group():
+        if backend == "nccl" and not pg_nccl:
+            torch.cuda.set_device(local_rank)
+            st["grp"] = dist.new_group(backend="nccl")
+
+    res_inlib = res_ranks = None
+    if both:
+        res_inlib = measure("inlib")
+        rccl_group()
+        if res_inlib is not None and rank == 0:
+            keep = dict(elapsed=res_inlib["elapsed"], proof=res_inlib["proof"].raw)
+            release(res_inlib)
+            res_inlib = keep
+        res_ranks = measure("ranks")
+        res = res_ranks
+        mode = "ranks"
+    else:
+        res = measure(mode)
+        if res is None:                       # forced in-library mode that failed under torch.distributed.run
+            rccl_group()
+            mode = "ranks"
+            res = res_ranks = measure("ranks")
+    fallback_reason = st["fallback_reason"]
+    active, prover, proof, elapsed = res["active"], res["prover"], res["proof"], res["elapsed"]
+    w_dev, w_ptr, zkey_path, dev, sampler = res["w_dev"], res["w_ptr"], res["zkey"], res["dev"], res["sampler"]
+    if res["pk"] is not None:
+        pk, mats, m = res["pk"], res["mats"], res["m"]
+    t_setup = time.time() - t_setup
     if not active or rank != 0:
         if dist:
             dist.barrier()          # rank 0's checker legs run while the others wait here
             dist.destroy_process_group()
         return
+    if args.pmc_child:                # the profiled child of measure_pmc_traffic(): the proofs above are all it is for
+        return
+    both_vals = None
+    if both:
+        both_vals = {"value_rccl": m * args.steps / res_ranks["elapsed"], "ms_per_step_rccl": res_ranks["elapsed"] / args.steps * 1e3,
+                     "value_inlib": None, "ms_per_step_inlib": None, "rccl_ranks": st["rccl_ranks"]}
+        if isinstance(res_inlib, dict):
+            both_vals["value_inlib"] = m * args.steps / res_inlib["elapsed"]
+            both_vals["ms_per_step_inlib"] = res_inlib["elapsed"] / args.steps * 1e3
+            both_vals["inlib_and_rccl_proofs_identical"] = bool(res_inlib["proof"] == proof.raw)
+            if res_inlib["elapsed"] < elapsed:
+                elapsed = res_inlib["elapsed"]       # `value` = the faster path; the checker legs below run on the RCCL path's proof
+                both_vals["value_is"] = "in-library"
+            else:
+                both_vals["value_is"] = "rccl"
     stages = prover.stage_times()
     prover.set_profiling(False)
     info = prover.info()
@@ -904,6 +1106,13 @@ def main():
                  "msm_B2_ms": timed(lambda: prover.msm_g2_dev(wptr + 32, n_vars - 1)),
                  "note": "each MSM = its own digit sort + bucket accumulation + reduction + affine result; "
                          "the full prove shares one sort among A, B1, L, B2 and overlaps the witness map"}
+
+    clock = None
+    if sampler:
+        sampler.stop()
+        clock = sampler.summary()
+        clock["note"] = ("`timed` = samples inside the timed region; `after` = the PCIe-inclusive and two-in-flight legs that "
+                         "follow it (continuous proving); DESIGN.md section 5: ~2.07-2.12 GHz under 2^22 proofs on a normal box")
 
     # ---------------- parity (outside the timed region; oracle = checker only) ----------------
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -1032,9 +1241,15 @@ def main():
     W_w, W_h = info["W_w"], info["W_h"]
     import hashlib
     lib_sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:16]
-    pmc, pmc_note = {}, "no PMC record for this size / workload"
+    pmc, pmc_note, pmc_live_note = {}, "no PMC record for this size / workload", None
+    if n_gpus == 1 and not args.no_pmc and args.mode == "prove" and not os.environ.get("G16_AMD_LIB"):
+        prover.close()                        # every timing leg is done: the profiled child gets the HBM
+        prover = None
+        rec, pmc_live_note = measure_pmc_traffic(args, k)
+        if rec:
+            pmc, pmc_note = rec, pmc_live_note
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if n_gpus == 1 and os.path.exists(tpath) and args.workload == "chain":
+    if not pmc and n_gpus == 1 and os.path.exists(tpath) and args.workload == "chain":
         t = json.load(open(tpath))
         if t.get("log2_domain") != k:
             pmc_note = f"profiles/pmc_traffic.json was measured at 2^{t.get('log2_domain')}"
@@ -1045,6 +1260,10 @@ def main():
             pmc = t
             pmc_note = (f"separate rocprofv3 --pmc passes (scripts/pmc_passes.sh) on library {lib_sha}, "
                         f"{t.get('measured', '?')}; NOT measured by this run")
+        if pmc_live_note:
+            pmc_note += f" [this run's own passes: {pmc_live_note}]"
+    elif not pmc and pmc_live_note:
+        pmc_note = pmc_live_note
 
     def kern(name, what, ms, cnt, bytes_per_point, npoints, madds, vmad_per_madd, tkey):
         if not cnt or ms <= 0:
@@ -1099,6 +1318,10 @@ def main():
         par = (f"{cut} x{n_gpus} + four-step witness map (2 all-to-all), "
                + ("one g16_ctx_create_multi ctx in one process: peer copies over xGMI inside the library"
                   if mode == "inlib" else "one process per GPU: RCCL all_to_all / all_gather, event hand-offs"))
+        if both_vals and both_vals.get("value_inlib"):
+            par = (f"{cut} x{n_gpus} + four-step witness map (2 all-to-all); BOTH launch shapes timed: one g16_ctx_create_multi "
+                   "ctx in one process (peer copies over xGMI inside the library) and one process per GPU (RCCL all_to_all / "
+                   f"all_gather, event hand-offs); `value` = the faster ({both_vals['value_is']})")
         if fallback_reason:
             par += " [fallback: the in-library ctx failed on this node]"
         if one_gpu:
@@ -1123,6 +1346,14 @@ def main():
                                "-> 256 B D2H; `value` keeps the witness resident in HBM (bench contract)",
         "library": lib_path,
     }
+    if both_vals:
+        out.update(both_vals)
+    elif n_gpus > 1:
+        out["rccl_ranks"] = st["rccl_ranks"]
+    if clock:
+        out["clock_mhz"] = clock["timed"]["sclk_mhz_median"] or clock["after"]["sclk_mhz_median"]
+        out["power_w"] = clock["timed"]["power_w_median"] or clock["after"]["power_w_median"]
+        out["clock"] = clock
     if pipelined:
         out["value_pipelined"] = pipelined
     if fallback_reason:

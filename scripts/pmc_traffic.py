@@ -27,7 +27,8 @@ def traffic(m):
     return read_bytes, write_bytes
 
 
-def main(root, log2, out):
+def collect(root, log2):
+    """per-launch traffic record from the counter_collection.csv files below `root` (one directory per pass)"""
     # single-query launches (L, H; every G1 launch when G16_NO_PAIR_AB=1) / the A|B1 pair launch
     acc, pair, g2_d = defaultdict(list), defaultdict(list), defaultdict(list)
     for path in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
@@ -62,6 +63,11 @@ def main(root, log2, out):
         rec.update({"g2_kernel": "k_bucket_accumulate<Fq2, 1, false> (B2 query)",
                     "g2_read_bytes_per_launch": gr, "g2_write_bytes_per_launch": gw,
                     "g2_traffic_bytes_per_launch": gr + gw, "g2_counters": mg})
+    return rec
+
+
+def main(root, log2, out):
+    rec = collect(root, log2)
     import datetime
     import hashlib
     lib = os.environ.get("G16_AMD_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),

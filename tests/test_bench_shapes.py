@@ -37,8 +37,16 @@ def test_bench_n_gt_1_shapes_on_one_gpu(gpulib, name, n, env):
     assert all(v for k, v in d["parity"].items() if k.startswith("bit_identical_to_cpu")), d["parity"]
     par = d["config"]["parallelism"]
     if name == "inlib":
-        assert "g16_ctx_create_multi" in par and not d.get("fallback_reason")
+        # the default under torch.distributed.run (round 5): BOTH launch shapes are timed on the same inputs,
+        # their proofs are identical, `value` is the faster; rccl_ranks = 0 here (gloo stands in for RCCL)
+        assert "g16_ctx_create_multi" in par and "one process per GPU" in par and not d.get("fallback_reason")
+        assert d["value_inlib"] > 0 and d["value_rccl"] > 0 and d["inlib_and_rccl_proofs_identical"]
+        assert d["value"] == pytest.approx(max(d["value_inlib"], d["value_rccl"]), rel=1e-6)
+        assert d["rccl_ranks"] == 0 and d["value_is"] in ("in-library", "rccl")
     elif name == "fallback":
         assert d.get("fallback_reason") and "one process per GPU" in par and "fallback" in par, (par, d.get("fallback_reason"))
     else:
         assert "one process per GPU" in par and "g16_ctx_create_multi" not in par, par
+        assert d["rccl_ranks"] == 0                     # gloo between the processes on this box
+    if name == "fallback":
+        assert d["value_rccl"] > 0 and d["value_inlib"] is None
