@@ -733,11 +733,29 @@ g16_status g16_ctx_create_sibling(g16_ctx* donor, const g16_key_desc* key, const
   return G16_OK;
 }
 
+// A ctx that still lends its point planes (g16_ctx_create_sibling; ranks of a multi-device ctx that
+// repeat a device ordinal) is not freed under its borrowers: the handle dies for the caller, the state
+// stays until the last borrower is destroyed (round 5; rounds 3-4 printed a warning and freed anyway).
+static std::mutex g_lend_mu;
+
 void g16_ctx_destroy(g16_ctx* c) {
   if (!c) return;
-  if (c->borrowers > 0)  // documented contract: the donor outlives its siblings; say so instead of corrupting them
-    fprintf(stderr, "libg16_amd: g16_ctx_destroy on a ctx that still lends its point planes to %d ctx(s)\n", c->borrowers);
-  if (c->share_from) --c->share_from->borrowers;
+  g16_ctx* lender = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_lend_mu);
+    if (c->borrowers.load() > 0) {
+      c->zombie = true;  // the last borrower's destroy comes back here
+      return;
+    }
+    if (c->share_from && c->share_from->borrowers.fetch_sub(1) == 1 && c->share_from->zombie) lender = c->share_from;
+    c->share_from = nullptr;
+  }
+  struct Then {  // the lender, if this was its last borrower and its owner has already let go of it
+    g16_ctx* l;
+    ~Then() {
+      if (l) g16_ctx_destroy(l);
+    }
+  } then{lender};
   if (c->multi) {  // parent of a multi-device prover: the children own all device state
     multi_destroy(c->multi);
     if (c->pinned_w) (void)hipHostFree(c->pinned_w);

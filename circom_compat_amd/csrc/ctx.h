@@ -1,6 +1,7 @@
 // ctx.h -- private definition of g16_ctx (the opaque handle of include/g16_amd.h), shared by
 // api.hip (per-device drivers) and multi.hip (single-process multi-device orchestration).
 #pragma once
+#include <atomic>
 #include "../../include/g16_amd.h"
 
 #include <memory>
@@ -80,8 +81,9 @@ struct g16_ctx {
   // parent of a single-process multi-device prover (g16_ctx_create_multi): holds no device state
   // of its own, only the per-device children and the exchange plumbing between them
   g16::Multi* multi = nullptr;
-  g16_ctx* share_from = nullptr;  // lender of the point planes (must outlive this ctx)
-  int borrowers = 0;              // live ctxs that borrow this one's planes
+  g16_ctx* share_from = nullptr;  // lender of the point planes (kept alive by `borrowers` below)
+  std::atomic<int> borrowers{0};  // live ctxs that borrow this one's planes (incremented from parallel create threads)
+  bool zombie = false;            // g16_ctx_destroy was called while borrowers > 0: freed by the last borrower's destroy
   uint64_t nnz_a = 0, nnz_b = 0;  // shape of the constraint matrices (g16_ctx_create_sibling checks them)
   uint32_t peer_state = 0;        // multi-device parent: 1 = every peer pair has direct access, 2 = some copies are staged
 

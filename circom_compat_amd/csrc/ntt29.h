@@ -12,9 +12,10 @@
 // [vector][limb][n].
 //
 // Value bookkeeping (asserted by F29_CHECK in the emulator build):
-//   DIF: the sum output x0 + x1 doubles per stage; every 5th stage of a pass multiplies the sum
-//        by one() and every pass ends with a multiplication of ALL elements (inter-pass twiddle,
-//        twist or one()), so |value| < 128 r at every product.
+//   DIF: the sum output x0 + x1 doubles per stage; every 6th stage of a pass multiplies the sum
+//        by one() (passes of <= 6 stages need none: 2 r * 2^6 = 128 r) and every pass ends with a
+//        multiplication of ALL elements (inter-pass twiddle, twist or one()), so |value| <= 128 r at
+//        every product (the contract allows 169 r against a canonical twiddle).
 //   DIT: x0 +- w x1 grows by at most 2 r per stage; every strided pass starts with a
 //        multiplication of all elements (inter-pass twiddle), so |value| < 24 r throughout.
 #pragma once
@@ -24,13 +25,23 @@
 namespace g16 {
 
 constexpr int NTT29_LIMBS = f29::N;
+constexpr int NTT29_FULL_TABLE_MAX_LOG = 24;   // 3 n x 32 B of tables: 1.5 GiB at 2^24
 
 struct Ntt29Plan {
   NttPlan base;                  // pass schedule + host-computed tables in the storage form
   DevBuf<Fr> tlo[2], thi[2];     // the same tables in the PACKED INTERNAL form (canonical x * 2^261)
   DevBuf<Fr> twlo, twhi, loc[2];
+  // Round 5: SINGLE-LEVEL tables (one product per twiddle instead of lo x hi, then the element) for
+  // log n <= NTT29_FULL_TABLE_MAX_LOG.  ptab[d][i]: the inter-pass twiddles of strided pass i in the
+  // order the pass touches them -- entry (kappa << lo) | c = omega_n^(+-(c kappa) << (k - hi)), 2^hi
+  // entries: n for the top pass (32 B per element and pass of extra HBM reads, contiguous in c),
+  // 2^16-ish (L2 resident) for the ones below.  twfull[i] = omega_2n^bitrev(i) / n: the coset twist of
+  // the CircomReduction map at the position the last DIF pass stores to.  2 n + n entries of 32 B.
+  DevBuf<Fr> ptab[2][4];
+  DevBuf<Fr> twfull;
+  bool full_tables = false;
   Fr n_inv_packed;               // 1/n, packed internal
-  void build(int log_n, hipStream_t stream);
+  void build(int log_n, hipStream_t stream, bool want_full_tables = true);
   // two-level table of scale * base^j, j < n, in the packed internal form (lo: 2^h1 entries of
   // base^l, hi: scale * base^(h 2^h1)); the plan's own twlo / twhi are make_twist(omega_2n, 1/n)
   void make_twist(Fr base, Fr scale, DevBuf<Fr>& lo, DevBuf<Fr>& hi) const;

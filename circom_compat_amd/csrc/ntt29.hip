@@ -30,6 +30,8 @@ struct Ntt29Args {
   int h1;
   const Fr* twlo;  // coset twist tables (twhi carries 1/n)
   const Fr* twhi;
+  const Fr* ptab;    // single-level inter-pass twiddles of THIS pass ((kappa << lo) | c), or null
+  const Fr* twfull;  // single-level coset twist at the stored position, or null
   int fuse;
   Fr scale;  // 1/n, packed internal
 };
@@ -93,8 +95,12 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt29_pass(Ntt29Args A) {
     if (DIT && A.lo != 0) {
       const uint32_t c = c_base | (uint32_t)t;
       const uint32_t kap = __brev((uint32_t)rho) >> (32 - A.b);
-      const uint32_t ex = (c * kap) << (A.k - hi);
-      x = x * two_level(A.tlo, A.thi, A.h1, ex);  // ex == 0 multiplies by one(): value back below 2 r
+      if (A.ptab) {
+        x = x * unpack_tw(A.ptab[(kap << A.lo) | c]);
+      } else {
+        const uint32_t ex = (c * kap) << (A.k - hi);
+        x = x * two_level(A.tlo, A.thi, A.h1, ex);  // ex == 0 multiplies by one(): value back below 2 r
+      }
     }
     s[e] = x;
     (void)rho;
@@ -106,7 +112,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt29_pass(Ntt29Args A) {
   for (int st = 0; st < A.b; ++st) {
     const int lm = DIT ? st : (A.b - 1 - st);  // log2 of the half-size
     const int m = 1 << lm;
-    const bool renorm = !DIT && ((st + 1) % 5 == 0) && (st + 1 < A.b);
+    const bool renorm = !DIT && ((st + 1) % 6 == 0) && (st + 1 < A.b);
     for (int u = tid; u < half; u += NTT_THREADS) {
       int j, t;
       if (A.lo == 0) {
@@ -157,12 +163,20 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt29_pass(Ntt29Args A) {
       if (A.lo != 0) {
         const uint32_t c = c_base | (uint32_t)t;
         const uint32_t kap = __brev((uint32_t)rho) >> (32 - A.b);
-        const uint32_t ex = (c * kap) << (A.k - hi);
-        x = x * two_level(A.tlo, A.thi, A.h1, ex);
+        if (A.ptab) {
+          x = x * unpack_tw(A.ptab[(kap << A.lo) | c]);
+        } else {
+          const uint32_t ex = (c * kap) << (A.k - hi);
+          x = x * two_level(A.tlo, A.thi, A.h1, ex);
+        }
       } else if (A.fuse == NTT_FUSE_TWIST_SCALE) {
-        const uint32_t j = A.k ? (__brev(gidx) >> (32 - A.k)) : 0u;
-        const uint32_t l = j & ((1u << A.h1) - 1u);
-        x = x * (unpack_tw(A.twlo[l]) * unpack_tw(A.twhi[j >> A.h1]));  // twhi carries 1/n
+        if (A.twfull) {
+          x = x * unpack_tw(A.twfull[gidx]);
+        } else {
+          const uint32_t j = A.k ? (__brev(gidx) >> (32 - A.k)) : 0u;
+          const uint32_t l = j & ((1u << A.h1) - 1u);
+          x = x * (unpack_tw(A.twlo[l]) * unpack_tw(A.twhi[j >> A.h1]));  // twhi carries 1/n
+        }
       } else if (A.fuse == NTT_FUSE_SCALE) {
         x = x * unpack_tw(A.scale);
       } else {
@@ -180,6 +194,26 @@ __global__ void k_table_to_internal(const Fr* in, Fr* out, uint32_t n) {
   if (i >= n) return;
   Fr r;
   Fr29::from_mont256(in[i]).pack_internal(r.v);
+  out[i] = r;
+}
+
+// single-level inter-pass table of one strided pass: out[(kappa << lo) | c] = omega^((c kappa) << shift)
+__global__ void k_build_pass_table(const Fr* tlo, const Fr* thi, int h1, int lo, int shift, uint32_t count,
+                                   Fr* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t c = i & ((1u << lo) - 1u), kap = i >> lo;
+  Fr r;
+  two_level(tlo, thi, h1, (c * kap) << shift).pack_internal(r.v);
+  out[i] = r;
+}
+// single-level coset twist: out[i] = twlo[l] * twhi[h] for j = bitrev_k(i) = h 2^h1 + l
+__global__ void k_build_twist_table(const Fr* twlo, const Fr* twhi, int h1, int k, uint32_t count, Fr* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t j = k ? (__brev(i) >> (32 - k)) : 0u;
+  Fr r;
+  (unpack_tw(twlo[j & ((1u << h1) - 1u)]) * unpack_tw(twhi[j >> h1])).pack_internal(r.v);
   out[i] = r;
 }
 
@@ -201,9 +235,10 @@ __global__ void k_bitrev_planes(const int32_t* in, int32_t* out, int k) {
   for (int l = 0; l < NTT29_LIMBS; ++l) out[(size_t)l * n + i] = in[(size_t)l * n + j];
 }
 
-void run_pass(const Ntt29Plan& P, const NttPass& ps, bool dit, bool inverse, int32_t* data,
+void run_pass(const Ntt29Plan& P, size_t pass_index, bool dit, bool inverse, int32_t* data,
               size_t vec_stride, int batch, int fuse, hipStream_t stream, const Fr* twlo = nullptr,
               const Fr* twhi = nullptr) {
+  const NttPass& ps = P.base.passes[pass_index];
   Ntt29Args A;
   A.data = data;
   A.vec_stride = vec_stride;
@@ -220,6 +255,8 @@ void run_pass(const Ntt29Plan& P, const NttPass& ps, bool dit, bool inverse, int
   A.h1 = P.base.h1;
   A.twlo = twlo ? twlo : P.twlo.p;
   A.twhi = twhi ? twhi : P.twhi.p;
+  A.ptab = (P.full_tables && ps.lo != 0) ? P.ptab[d][pass_index].p : nullptr;
+  A.twfull = (P.full_tables && !twlo) ? P.twfull.p : nullptr;  // a caller's own twist tables stay two-level
   A.fuse = fuse;
   A.scale = P.n_inv_packed;
   const size_t E = (size_t)1 << (ps.b + ps.logT);
@@ -240,8 +277,9 @@ void convert_table(const DevBuf<Fr>& in, DevBuf<Fr>& out, hipStream_t stream) {
 
 }  // namespace
 
-void Ntt29Plan::build(int log_n, hipStream_t stream) {
+void Ntt29Plan::build(int log_n, hipStream_t stream, bool want_full_tables) {
   base.build(log_n);
+  full_tables = false;
   for (int d = 0; d < 2; ++d) {
     convert_table(base.tlo[d], tlo[d], stream);
     convert_table(base.thi[d], thi[d], stream);
@@ -250,6 +288,26 @@ void Ntt29Plan::build(int log_n, hipStream_t stream) {
   convert_table(base.twlo, twlo, stream);
   convert_table(base.twhi, twhi, stream);
   Fr29::from_mont256(base.n_inv).pack_internal(n_inv_packed.v);  // host arithmetic
+  // G16_NTT_TWO_LEVEL=1 (diagnostic, tested): the two-level tables every plan above 2^24 uses, at any size
+  const char* two_level_only = getenv("G16_NTT_TWO_LEVEL");
+  if (two_level_only && two_level_only[0] == '1') want_full_tables = false;
+  if (want_full_tables && base.k >= 1 && base.k <= NTT29_FULL_TABLE_MAX_LOG && base.passes.size() <= 4) {
+    for (int d = 0; d < 2; ++d)
+      for (size_t i = 0; i < base.passes.size(); ++i) {
+        const NttPass& ps = base.passes[i];
+        if (ps.lo == 0) continue;
+        const int hi = ps.lo + ps.b;
+        const uint32_t count = 1u << hi;
+        ptab[d][i].alloc(count);
+        G16_LAUNCH(k_build_pass_table, ceil_div(count, 256), 256, 0, stream, (const Fr*)tlo[d].p,
+                   (const Fr*)thi[d].p, base.h1, ps.lo, base.k - hi, count, ptab[d][i].p);
+      }
+    const uint32_t n = (uint32_t)base.n;
+    twfull.alloc(n);
+    G16_LAUNCH(k_build_twist_table, ceil_div(n, 256), 256, 0, stream, (const Fr*)twlo.p, (const Fr*)twhi.p,
+               base.h1, base.k, n, twfull.p);
+    full_tables = true;
+  }
   G16_HIP(hipStreamSynchronize(stream));
 }
 
@@ -258,8 +316,7 @@ void ntt29_dif(const Ntt29Plan& P, int32_t* data, size_t vec_stride, int batch, 
   if (P.base.k == 0) return;
   for (size_t i = 0; i < P.base.passes.size(); ++i) {
     const bool last = (i + 1 == P.base.passes.size());
-    run_pass(P, P.base.passes[i], false, inverse, data, vec_stride, batch, last ? (int)fuse : 0,
-             stream, twlo, twhi);
+    run_pass(P, i, false, inverse, data, vec_stride, batch, last ? (int)fuse : 0, stream, twlo, twhi);
   }
 }
 
@@ -291,7 +348,7 @@ void Ntt29Plan::make_twist(Fr g, Fr scale, DevBuf<Fr>& lo, DevBuf<Fr>& hi) const
 void ntt29_dit(const Ntt29Plan& P, int32_t* data, size_t vec_stride, int batch, hipStream_t stream) {
   if (P.base.k == 0) return;
   for (size_t i = P.base.passes.size(); i-- > 0;)
-    run_pass(P, P.base.passes[i], true, false, data, vec_stride, batch, 0, stream);
+    run_pass(P, i, true, false, data, vec_stride, batch, 0, stream);
 }
 
 void ntt29_to_planes(const Fr* in, int32_t* planes, size_t n, hipStream_t stream) {

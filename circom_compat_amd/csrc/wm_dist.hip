@@ -204,7 +204,7 @@ void WmDist::init(const CsrHost& A, const CsrHost& B, uint32_t m_, uint32_t num_
     throw std::runtime_error("domain too small for a distributed witness map on this many ranks");
   c2 = n2 / world;
   r1 = n1 / world;
-  planN.build(k, nullptr);
+  planN.build(k, nullptr, /*want_full_tables=*/false);  // only its two-level omega tables are read
   plan1.build(k1, nullptr);
   plan2.build(k2, nullptr);
   auto up = [&](const CsrHost& h, CsrStore& d) {

@@ -131,8 +131,10 @@ void g16_ctx_destroy(g16_ctx* ctx);
  * (no second copy of the 21 GiB at 2^22) and owns everything else (streams, sort state, workspaces):
  * two host threads can then keep two proofs in flight, one per ctx -- the front of one (digit sort,
  * witness map) runs under the bucket reductions and the finalisation of the other.  key / a / b as
- * given to the donor (the descriptor's query pointers are not read again); the donor must outlive
- * the sibling.  Throughput mode of a proving service; one proof's latency does not change.        */
+ * given to the donor (the descriptor's query pointers are not read again).  The planes are reference
+ * counted: g16_ctx_destroy(donor) while siblings live only retires the donor's HANDLE (it must not be
+ * used again) -- its device state is freed by the destroy of the last sibling.  Throughput mode of a
+ * proving service; one proof's latency does not change.                                            */
 g16_status g16_ctx_create_sibling(g16_ctx* donor, const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
                                   uint32_t num_constraints, const g16_options* opt, g16_ctx** out);
 const char* g16_last_error(const g16_ctx* ctx); /* ctx may be NULL: error of the last failed create */

@@ -1,5 +1,8 @@
 //! The reference's bench (benches/groth16.rs:13-85) with the GPU prover: same key file, same
 //! witness calculator, same verification, same `groth proof {i} {j}` bench id.
+//
+// Derived from arkworks-rs/circom-compat (bench at benches/groth16.rs), Copyright (c) 2021 Georgios Konstantopoulos,
+// licensed MIT OR Apache-2.0; this file keeps that licence (see the crate's Cargo.toml).
 use criterion::{black_box, criterion_group, criterion_main, Criterion};
 
 use ark_bn254::{Bn254, Fr};
@@ -47,8 +50,27 @@ fn bench_groth(c: &mut Criterion, num_validators: u32, num_constraints: u32) {
     });
 }
 
-fn groth(c: &mut Criterion) {
-    bench_groth(c, 10000, 10000);
+// the reference's sweep (benches/groth16.rs:87-108): 10^i variables x 10^j constraints, 3 <= i <= j <= 5,
+// under the same feature name; scripts/bench_sweep.py runs the same six shapes through the C ABI
+cfg_if::cfg_if! {
+    if #[cfg(feature = "bench-complex-all")] {
+        const MIN_NUM_VARIABLES_POWER: u32 = 3;
+        const MAX_NUM_VARIABLES_POWER: u32 = 5;
+        const MAX_NUM_CONSTRAINTS_POWER: u32 = 5;
+        fn groth_all(c: &mut Criterion) {
+            for i in MIN_NUM_VARIABLES_POWER..=MAX_NUM_VARIABLES_POWER {
+                for j in i..=MAX_NUM_CONSTRAINTS_POWER {
+                    bench_groth(c, 10_u32.pow(i), 10_u32.pow(j));
+                }
+            }
+        }
+        criterion_group!(benches, groth_all);
+    } else {
+        fn groth(c: &mut Criterion) {
+            bench_groth(c, 10000, 10000);
+        }
+        criterion_group!(benches, groth);
+    }
 }
-criterion_group!(benches, groth);
+
 criterion_main!(benches);

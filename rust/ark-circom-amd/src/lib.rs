@@ -35,7 +35,10 @@ use ark_std::rand::Rng;
 use ark_std::UniformRand;
 
 /// The two entry points of `Groth16::<Bn254, CircomReduction>` that sit on the proving path, with the
-/// reference's argument meaning (benches/groth16.rs:52-60, src/zkey.rs:866).
+/// reference's argument meaning (benches/groth16.rs:52-60, src/zkey.rs:866).  The error type is
+/// `GpuError` (`Synthesis(SynthesisError)` for everything the CPU path can report, `Library(code,
+/// message)` for device failures; it implements `std::error::Error`, so `?` into `Box<dyn Error>` /
+/// `color_eyre::Result` -- what the reference's tests and README use -- keeps compiling).
 pub struct Groth16Gpu;
 
 impl Groth16Gpu {
@@ -48,11 +51,11 @@ impl Groth16Gpu {
         num_inputs: usize,
         num_constraints: usize,
         full_assignment: &[Fr],
-    ) -> Result<Proof<Bn254>, SynthesisError> {
+    ) -> Result<Proof<Bn254>, GpuError> {
         if num_inputs != prover.num_inputs() || num_constraints != prover.num_constraints() {
-            return Err(SynthesisError::MalformedVerifyingKey);
+            return Err(GpuError::Synthesis(SynthesisError::MalformedVerifyingKey));
         }
-        prover.create_proof(r, s, full_assignment).map_err(Into::into)
+        prover.create_proof(r, s, full_assignment)
     }
 
     /// `SNARK::prove(&pk, circuit, rng)`: r, s from the rng; the assignment is the one
@@ -64,7 +67,7 @@ impl Groth16Gpu {
         prover: &mut GpuProver,
         circuit: CircomCircuit<Fr>,
         rng: &mut R,
-    ) -> Result<Proof<Bn254>, SynthesisError> {
+    ) -> Result<Proof<Bn254>, GpuError> {
         let w = circuit.witness.as_ref().ok_or(SynthesisError::AssignmentMissing)?;
         let n = circuit.r1cs.num_inputs + circuit.r1cs.num_aux;
         let assignment: Vec<Fr> = match &circuit.r1cs.wire_mapping {
@@ -73,6 +76,6 @@ impl Groth16Gpu {
         };
         let r = Fr::rand(rng);
         let s = Fr::rand(rng);
-        prover.create_proof(r, s, &assignment).map_err(Into::into)
+        prover.create_proof(r, s, &assignment)
     }
 }

@@ -29,15 +29,24 @@ pub enum GpuError {
     /// anything else the library reports (status code, message)
     Library(i32, String),
 }
-impl From<GpuError> for SynthesisError {
-    fn from(e: GpuError) -> Self {
-        match e {
-            GpuError::Synthesis(s) => s,
-            // the reference's signature only has SynthesisError: a device failure is "unexpected"
-            GpuError::Library(..) => SynthesisError::Unsatisfiable,
+impl std::fmt::Display for GpuError {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        match self {
+            GpuError::Synthesis(s) => write!(f, "{s}"),
+            GpuError::Library(code, msg) => write!(f, "libg16_amd status {code}: {msg}"),
         }
     }
 }
+impl std::error::Error for GpuError {}
+impl From<SynthesisError> for GpuError {
+    fn from(e: SynthesisError) -> Self {
+        GpuError::Synthesis(e)
+    }
+}
+// Deliberately NO `impl From<GpuError> for SynthesisError` (round 5): no SynthesisError variant means
+// "the device failed", and rounds 2-4 squeezed a HIP out-of-memory into `Unsatisfiable`.  Everything in
+// this crate that can meet a device failure returns `GpuError`; the one place that has to return
+// `SynthesisError` (the `R1CSToQAP` impl in reduction.rs) logs the library's message first.
 
 pub struct GpuProver {
     ctx: *mut ffi::g16_ctx,

@@ -2,16 +2,24 @@
 //! reference src/circom/qap.rs:14-106) whose `witness_map_from_matrices` runs on the GPU.
 //!
 //! The trait is stateless (static methods, no `self`), so the resident state lives in a
-//! thread-local cache.  Identifying "the same matrices" has to be both cheap and safe:
-//!   * fast path (every call): the addresses and lengths of the outer `Vec`s and of their first rows
-//!     match the cached ones AND a fixed sample of 64 rows compares equal element for element --
-//!     O(1), no hashing.  (An address alone would be reused by a freed-and-reallocated `Vec` of the
-//!     same shape and silently pair a stale device ctx with new matrices; the row sample catches that
-//!     for anything but an adversarially similar matrix, and the slow path below settles it.)
-//!   * slow path (addresses or shape changed): a 128-bit content hash over every row's indices and
-//!     the coefficients' raw Montgomery limbs, eight bytes per step (no `into_bigint()`: one Montgomery
-//!     reduction per coefficient cost more than the GPU witness map it guards) -- equal hash: the ctx is
-//!     kept and re-bound to the new addresses; different: A and B are packed and uploaded again.
+//! thread-local cache keyed by the CONTENT of the matrices:
+//!   * default (safe): every call hashes every row -- a 128-bit hash over the row lengths, the wire
+//!     indices and the coefficients' raw Montgomery limbs, eight bytes per step (no `into_bigint()`:
+//!     one Montgomery reduction per coefficient would cost more than the GPU witness map it guards).
+//!     Equal hash and shape: the device ctx is reused; anything else: A and B are packed and uploaded
+//!     again.  A matrix mutated in place, or a near-identical one reallocated at the same addresses,
+//!     can therefore never meet a stale ctx (round 4's address + 64-row-sample shortcut could).
+//!   * opt-in (`GpuCircomReduction::trust_unchanged_matrices(true)`, per thread): for callers that
+//!     GUARANTEE the matrices behind an address are not mutated while cached (the usual prove loop
+//!     over one key).  The hash is then skipped when the addresses and lengths of the outer `Vec`s and
+//!     of their first rows, the shape (rows, total nnz of A and of B) and a sample of 64 rows all match
+//!     -- O(rows) for the nnz count, no hashing.  `GpuCircomReduction::invalidate()` drops the cached
+//!     ctx explicitly.
+//! Errors: device / library failures surface as `GpuError::Library(code, message)` from
+//! `GpuCircomReduction::try_witness_map`; the `R1CSToQAP` impl has only `SynthesisError` to return, so
+//! it prints the library's message (`g16_last_error`) to stderr and returns
+//! `SynthesisError::UnexpectedIdentity` -- never `Unsatisfiable`: an out-of-memory device is not an
+//! unsatisfiable circuit.
 //! The MSMs inside `ark_groth16` are not overridable through this trait -- use `GpuProver` /
 //! `Groth16Gpu` for the whole proof; this impl exists for callers that only want `h`.
 use std::any::TypeId;
@@ -26,8 +34,46 @@ use ark_relations::r1cs::{ConstraintMatrices, ConstraintSystemRef, SynthesisErro
 
 use crate::ffi;
 use crate::pack::{self, Csr};
+use crate::prover::GpuError;
 
 pub struct GpuCircomReduction;
+
+thread_local! {
+    static TRUST_UNCHANGED: std::cell::Cell<bool> = std::cell::Cell::new(false);
+}
+
+impl GpuCircomReduction {
+    /// Per-thread opt-in to the address + sample fast path (module docs): only for callers that do
+    /// not mutate or replace-in-place the matrices while they are cached.
+    pub fn trust_unchanged_matrices(on: bool) {
+        TRUST_UNCHANGED.with(|t| t.set(on));
+    }
+    /// Drop this thread's cached device ctx (the next call uploads A and B again).
+    pub fn invalidate() {
+        CACHE.with(|c| *c.borrow_mut() = None);
+    }
+    /// `witness_map_from_matrices` for BN254 with the library's own error type.
+    pub fn try_witness_map(
+        matrices: &ConstraintMatrices<Fr>,
+        num_inputs: usize,
+        num_constraints: usize,
+        full_assignment: &[Fr],
+    ) -> Result<Vec<Fr>, GpuError> {
+        gpu_witness_map(matrices, num_inputs, num_constraints, full_assignment)
+    }
+}
+
+fn total_nnz(m: &ConstraintMatrices<Fr>) -> (usize, usize) {
+    (m.a.iter().map(|r| r.len()).sum(), m.b.iter().map(|r| r.len()).sum())
+}
+
+fn lib_error(ctx: *const ffi::g16_ctx, st: std::os::raw::c_int) -> GpuError {
+    if st == ffi::G16_ERR_DOMAIN_TOO_LARGE {
+        return GpuError::Synthesis(SynthesisError::PolynomialDegreeTooLarge);
+    }
+    let msg = unsafe { std::ffi::CStr::from_ptr(ffi::g16_last_error(ctx)).to_string_lossy().into_owned() };
+    GpuError::Library(st, msg)
+}
 
 /// where the matrices live: outer Vec addresses / lengths and the first rows' addresses
 #[derive(Clone, Copy, PartialEq, Eq)]
@@ -75,6 +121,7 @@ fn sample_matches(m: &ConstraintMatrices<Fr>, s: &RowSample) -> bool {
 
 struct WmCtx {
     key: ((u64, u64), usize, usize, usize), // (content hash of A and B, num_constraints, num_inputs, n_vars)
+    nnz: (usize, usize),
     ident: Ident,
     sample: RowSample,
     ctx: *mut ffi::g16_ctx,
@@ -124,15 +171,20 @@ fn gpu_witness_map(
     num_inputs: usize,
     num_constraints: usize,
     full_assignment: &[Fr],
-) -> Result<Vec<Fr>, SynthesisError> {
+) -> Result<Vec<Fr>, GpuError> {
     let ident = ident_of(matrices);
     let shape = (num_constraints, num_inputs, full_assignment.len());
+    let trust = TRUST_UNCHANGED.with(|t| t.get());
     CACHE.with(|cell| {
         let mut slot = cell.borrow_mut();
-        // fast path: same place, same shape, and the row sample still reads the same
-        let hit = slot.as_ref().map_or(false, |c| {
-            c.ident == ident && (c.key.1, c.key.2, c.key.3) == shape && sample_matches(matrices, &c.sample)
-        });
+        // opt-in fast path: same place, same shape (incl. total nnz), and the row sample still reads the same
+        let hit = trust
+            && slot.as_ref().map_or(false, |c| {
+                c.ident == ident
+                    && (c.key.1, c.key.2, c.key.3) == shape
+                    && c.nnz == total_nnz(matrices)
+                    && sample_matches(matrices, &c.sample)
+            });
         let mut key = ((0u64, 0u64), shape.0, shape.1, shape.2);
         if !hit {
             key.0 = content_hash(matrices);
@@ -167,19 +219,17 @@ fn gpu_witness_map(
             };
             let mut ctx: *mut ffi::g16_ctx = std::ptr::null_mut();
             let st = unsafe { ffi::g16_ctx_create(&desc, &va, &vb, num_constraints as u32, std::ptr::null(), &mut ctx) };
-            match st {
-                ffi::G16_OK => {}
-                ffi::G16_ERR_DOMAIN_TOO_LARGE => return Err(SynthesisError::PolynomialDegreeTooLarge),
-                _ => return Err(SynthesisError::Unsatisfiable),
+            if st != ffi::G16_OK {
+                return Err(lib_error(std::ptr::null(), st)); // create errors live in the library's global slot
             }
-            *slot = Some(WmCtx { key, ident, sample: sample_of(matrices), ctx, domain_size });
+            *slot = Some(WmCtx { key, nnz: total_nnz(matrices), ident, sample: sample_of(matrices), ctx, domain_size });
         }
         let c = slot.as_ref().unwrap();
         let w = pack::fr_vec_words(full_assignment);
         let mut h = vec![0u64; 4 * c.domain_size];
         let st = unsafe { ffi::g16_witness_map(c.ctx, w.as_ptr(), full_assignment.len(), h.as_mut_ptr()) };
         if st != ffi::G16_OK {
-            return Err(SynthesisError::Unsatisfiable);
+            return Err(lib_error(c.ctx, st));
         }
         Ok(h.chunks_exact(4).map(|l| Fr::new_unchecked(ark_ff::BigInt([l[0], l[1], l[2], l[3]]))).collect())
     })
@@ -205,7 +255,14 @@ impl R1CSToQAP for GpuCircomReduction {
             // F is ark_bn254::Fr: the casts below are identity casts
             let m = unsafe { &*(matrices as *const ConstraintMatrices<F> as *const ConstraintMatrices<Fr>) };
             let w = unsafe { std::slice::from_raw_parts(full_assignment.as_ptr() as *const Fr, full_assignment.len()) };
-            let h = gpu_witness_map(m, num_inputs, num_constraints, w)?;
+            let h = gpu_witness_map(m, num_inputs, num_constraints, w).map_err(|e| match e {
+                GpuError::Synthesis(s) => s,
+                GpuError::Library(code, msg) => {
+                    // the trait offers no "device failure" variant; say what happened where a log will keep it
+                    eprintln!("ark-circom-amd: libg16_amd failed in witness_map_from_matrices (status {code}): {msg}");
+                    SynthesisError::UnexpectedIdentity
+                }
+            })?;
             let h = std::mem::ManuallyDrop::new(h);
             // Vec<Fr> -> Vec<F>, same type
             return Ok(unsafe { Vec::from_raw_parts(h.as_ptr() as *mut F, h.len(), h.capacity()) });

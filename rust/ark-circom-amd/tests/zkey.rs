@@ -1,6 +1,9 @@
 //! The reference's two zkey integration tests (src/zkey.rs:846-919) with the GPU prover in the
 //! place of `Groth16::<Bn254, CircomReduction>`; everything else is the reference's own code path.
 //! Run from the ark-circom checkout root (the tests read ./test-vectors/...).
+//
+// Derived from arkworks-rs/circom-compat (tests at src/zkey.rs:846-919), Copyright (c) 2021 Georgios Konstantopoulos,
+// licensed MIT OR Apache-2.0; this file keeps that licence (see the crate's Cargo.toml).
 use std::{collections::HashMap, fs::File};
 
 use ark_bn254::{Bn254, Fr};

@@ -38,6 +38,43 @@ def test_ntt_vs_oracle(lib, k):
     assert _ntt(lib, x, False, 3) == o.ntt(x)
 
 
+@pytest.mark.parametrize("two_level", [False, True])
+@pytest.mark.parametrize("k", [13, 16, 17])
+def test_ntt29_multi_pass_single_level_and_two_level_tables(lib, monkeypatch, k, two_level):
+    """The witness map's NTT with strided passes of 3 .. 7 stages (2^16: two passes of 6 stages run
+    without the mid-pass value renormalisation since round 5; 2^17: a 7-stage pass keeps it), with the
+    round-5 single-level twiddle tables (one product per inter-pass twiddle, the default up to 2^24) and
+    with the two-level tables every larger plan uses (G16_NTT_TWO_LEVEL=1): DIF forward / inverse and DIT
+    == the oracle's plain radix-2 transform; the emulator build asserts the limb / value bounds."""
+    if two_level:
+        monkeypatch.setenv("G16_NTT_TWO_LEVEL", "1")
+    rng = random.Random(100 + k)
+    x = H.rand_fr(rng, 1 << k)
+    want_f, want_i = o.ntt(x), o.ntt(x, inverse=True)
+    assert _ntt(lib, x, False, 2) == want_f
+    assert _ntt(lib, x, True, 2) == want_i
+    assert _ntt(lib, x, False, 3) == want_f
+    if k == 16 and not two_level:       # the value bookkeeping at its extreme: every sum doubles
+        ones = [o.R_MOD - 1] * (1 << k)
+        assert _ntt(lib, ones, True, 2) == o.ntt(ones, inverse=True)
+        assert _ntt(lib, ones, False, 3) == o.ntt(ones)
+
+
+@pytest.mark.parametrize("two_level", [False, True])
+def test_witness_map_multi_pass_2p12_both_table_modes(lib, monkeypatch, two_level):
+    """CircomReduction::witness_map_from_matrices (qap.rs:23-88) at 2^12 rows -- a strided pass, the
+    contiguous pass and the coset twist fused into the last inverse pass -- element for element == the
+    oracle, with the single-level tables (twist read at the stored position) and the two-level ones."""
+    import circom_compat_amd as cc
+    if two_level:
+        monkeypatch.setenv("G16_NTT_TWO_LEVEL", "1")
+    cons, w, n_vars, _ = H.squaring_chain(12)
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, lib)
+    h = cc.CircomReduction.witness_map_from_matrices(mats, 2, len(cons), w, lib=lib)
+    assert H.fr_from_mont_arr(h) == o.witness_map_from_matrices(a_rows, b_rows, 2, len(cons), w)
+
+
 def test_ntt_lazy_limbs_edge_values(lib):
     """all-zero, all (r-1) and a single spike: the value-drift bookkeeping of ntt29.hip is exercised at
     its extremes (the emulator build asserts the limb / value bounds on every product)"""
@@ -846,6 +883,41 @@ def test_poseidon_chain_one_hash_public_output_is_the_circomlibjs_kat(lib):
     pr.close()
     assert o.verify_proof(opk, [kat], H.proof_from_bytes(proof.raw))
     assert not o.verify_proof(opk, [kat + 1], H.proof_from_bytes(proof.raw))
+
+
+def test_donor_destroyed_before_its_sibling_keeps_the_planes_alive(lib):
+    """g16_ctx_destroy on a ctx that still lends its point planes retires the handle only: the sibling
+    keeps proving (oracle bytes) and frees the donor's state with its own destroy (round 5; rounds 3-4
+    warned and freed under the borrower: dangling plane pointers).  A second sibling created and closed
+    in between leaves the count right.  Under scripts/asan_emu.sh a use-after-free is a report."""
+    import gc
+    import circom_compat_amd as cc
+    cons, w, n_vars, n_pub = H.squaring_chain(6)
+    rng = random.Random(56)
+    opk = o.trapdoor_setup(cons, n_vars, n_pub, *[rng.randrange(1, o.R_MOD) for _ in range(5)])
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, lib)
+    pk = H.pk_from_oracle(opk)
+    donor = cc.Prover(pk, mats, lib=lib)
+    sib = cc.Prover(pk, mats, lib=lib, sibling_of=donor)
+    sib2 = cc.Prover(pk, mats, lib=lib, sibling_of=donor)
+    sib2.close()
+    sib._donor = None                      # drop the Python-side keep-alive: the C library has to cope
+    donor.close()
+    del donor
+    gc.collect()
+    for _ in range(2):
+        r, s = rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)
+        want = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2,
+                                                                           len(cons), w))
+        assert sib.prove(r, s, w).raw == want
+    sib.close()                            # frees the sibling, then the retired donor
+    # a fresh donor / sibling pair after all that still works (nothing was left half-freed)
+    d2 = cc.Prover(pk, mats, lib=lib)
+    s2 = cc.Prover(pk, mats, lib=lib, sibling_of=d2)
+    assert s2.prove(r, s, w).raw == want and d2.prove(r, s, w).raw == want
+    s2.close()
+    d2.close()
 
 
 def test_sibling_ctx_shares_planes_two_proofs_in_flight(lib, golden):
