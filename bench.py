@@ -597,22 +597,29 @@ class ClockSampler:
         self._th = None
         if ordinal is None:
             return
-        cards = []
-        for c in sorted(glob.glob("/sys/class/drm/card[0-9]*"), key=lambda x: int(x.rsplit("card", 1)[1])):
-            try:
-                if open(os.path.join(c, "device", "vendor")).read().strip() != "0x1002":
-                    continue
-            except OSError:
-                continue
-            hw = sorted(glob.glob(os.path.join(c, "device", "hwmon", "hwmon*")))
-            if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
-                cards.append(hw[0])
+        # The host may expose more GPUs in sysfs than this container can open (one per tenant): the card
+        # that IS HIP device `ordinal` is the one whose PCI address hipDeviceGetPCIBusId reports.
+        hwmon = None
+        try:
+            import ctypes
+            buf = ctypes.create_string_buffer(64)
+            hip = ctypes.CDLL("libamdhip64.so")
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(ordinal)) == 0:
+                want = buf.value.decode().lower()
+                for c in glob.glob("/sys/class/drm/card[0-9]*"):
+                    if os.path.basename(os.path.realpath(os.path.join(c, "device"))).lower() == want:
+                        hw = sorted(glob.glob(os.path.join(c, "device", "hwmon", "hwmon*")))
+                        if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+                            hwmon = hw[0]
+                        break
+        except Exception:  # noqa: BLE001 -- no sysfs view of the device: rocm-smi below
+            hwmon = None
         self._freq = self._pow = None
-        if ordinal < len(cards):
-            self._freq = os.path.join(cards[ordinal], "freq1_input")
+        if hwmon:
+            self._freq = os.path.join(hwmon, "freq1_input")
             for name in ("power1_average", "power1_input"):
-                if os.path.exists(os.path.join(cards[ordinal], name)):
-                    self._pow = os.path.join(cards[ordinal], name)
+                if os.path.exists(os.path.join(hwmon, name)):
+                    self._pow = os.path.join(hwmon, name)
                     break
             self.source = f"sysfs {self._freq}" + (f" + {os.path.basename(self._pow)}" if self._pow else "")
         else:
@@ -1273,7 +1280,7 @@ def main():
         ach = algb / (per * 1e-3) / 1e9
         return {"kernel": name, "what": what, "avg_launch_ms": per, "launches_per_step": cnt / args.steps,
                 "algorithmic_bytes_per_launch": algb, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc.get(tkey), "mixed_additions_per_s": madds / (per * 1e-3),
+                "traffic": pmc.get(tkey) if tkey else None, "mixed_additions_per_s": madds / (per * 1e-3),
                 "vmad_frac_of_issue_peak": madds * vmad_per_madd / (per * 1e-3) / 30.1e12}
     VMAD_G1, VMAD_G2 = 1557.0, 4878.0          # multiply-adds per mixed addition
     if pair_cnt:
@@ -1286,6 +1293,15 @@ def main():
                   pair_cnt, 160, shard_w, 2 * shard_w * W_w, VMAD_G1, "pair_traffic_bytes_per_launch"),
              kern("k_bucket_accumulate<Fq, 1, false>", "L and H queries" if pair_cnt else "A, B1, L, H queries",
                   acc_ms, acc_cnt, 96, g1_len, g1_madds, VMAD_G1, "traffic_bytes_per_launch")]
+    # small keys (g16_options.fixed_tables, automatic): the MSMs are table lookups + tree sums (csrc/msm_table.hip);
+    # a stage span there = k_tbl_msm + k_tbl_final of one launch pair
+    tg1_ms, tg1_cnt = stages.get("msm_table_g1", (0.0, 0))
+    tg2_ms, tg2_cnt = stages.get("msm_table_g2", (0.0, 0))
+    if tg1_cnt or tg2_cnt:
+        kerns += [kern("k_tbl_msm<Fq2, 128> + k_tbl_final", "B2 query through fixed-base tables (32 lookups per point)",
+                       tg2_ms, tg2_cnt, 160, shard_w, shard_w * 32, VMAD_G2, None),
+                  kern("k_tbl_msm<Fq, 256> + k_tbl_final", "A, B1, L, s*A, r*B1 in one launch pair; H in another",
+                       tg1_ms, tg1_cnt, 96, (3 * shard_w + shard_h) / 2.0, (5 * shard_w + shard_h) * 32 / 2.0, VMAD_G1, None)]
     kerns = [x for x in kerns if x]
     head = max(kerns, key=lambda x: x["avg_launch_ms"])        # the per-step dominant launch
     tot_b = sum(x["algorithmic_bytes_per_launch"] * x["launches_per_step"] for x in kerns)
@@ -1304,6 +1320,9 @@ def main():
                         "not HBM bound: see `alu` and DESIGN.md section 4-5"}
     # supplementary: the same launches against the micro-benchmarked integer multiply-add issue peak
     g1k = next((x for x in kerns if x["kernel"].startswith("k_bucket_accumulate<Fq, 1")), head)
+    if tg1_cnt or tg2_cnt:
+        roofline["note"] = ("small key: every MSM is table lookups + a tree sum (latency bound: ~21 dependent EC additions per MSM); "
+                            "the HBM fraction of a 1 ms proof says nothing -- see ms_per_step")
     alu = {"kernel": g1k["kernel"], "mixed_additions_per_s": g1k["mixed_additions_per_s"],
            "vmad_peak_per_s": 30.1e12, "frac": g1k["vmad_frac_of_issue_peak"],
            "alu_only_ceiling_mixed_additions_per_s": 16.7e9,

@@ -386,6 +386,9 @@ class Proof:
         return f"Proof({self.raw.hex()[:32]}...)"
 
 
+DEFAULT_TABLES = 0     # g16_options.fixed_tables when Prover(tables=None): 0 = the library decides
+
+
 class Prover:
     """Device-resident (pk, matrices): the state create_proof_with_reduction_and_matrices borrows
     on every call in the reference, uploaded and precomputed once here (g16_ctx_create)."""
@@ -394,14 +397,17 @@ class Prover:
                  world=1, window_bits=0, planes=0, lib: Optional[B.Library] = None,
                  n_vars: Optional[int] = None, dist_wm=False, reduction: str = "circom",
                  devices: Optional[Sequence[int]] = None, shard: str = "auto",
-                 sibling_of: Optional["Prover"] = None):
+                 sibling_of: Optional["Prover"] = None, tables: Optional[int] = None):
         """devices=[d0, d1, ...]: ONE ctx sharded over several GPUs inside the library
         (g16_ctx_create_multi); prove() / prove_dev() are then used exactly as on one device.
         shard (world > 1 / devices): "points" = point-range MSM shards, "buckets" = every rank holds
         all points of the witness queries and 1/world of their sorted bucket list (H stays cut by
         point range), "auto" = points.
         sibling_of=prover: a second ctx on the same device that borrows `prover`'s point planes
-        (g16_ctx_create_sibling): two threads, two proofs in flight."""
+        (g16_ctx_create_sibling): two threads, two proofs in flight.
+        tables (g16_options.fixed_tables): None / 0 = automatic (small single-device keys prove through
+        fixed-base tables), 1 = require, -1 = never; DEFAULT_TABLES overrides None (the test-suite pins
+        the bucket path that way)."""
         self.lib = lib or B.load()
         self.matrices = matrices
         self.pk = pk
@@ -427,6 +433,7 @@ class Prover:
         opt.dist_wm = 1 if dist_wm else 0
         opt.reduction = REDUCTIONS[reduction]
         opt.shard = SHARD_MODES[shard]
+        opt.fixed_tables = DEFAULT_TABLES if tables is None else int(tables)
         self.dist_wm = bool(opt.dist_wm)
         self.rank, self.world = rank, world
         a, b = matrices.a.to_c(), matrices.b.to_c()
@@ -602,7 +609,7 @@ class Prover:
         out = (C.c_uint32 * 16)()
         self.lib.check(self.lib.g16_ctx_info(self.ctx, out), self.ctx)
         keys = ["c_w", "W_w", "planes_w", "D_w", "c_h", "W_h", "planes_h", "D_h", "domain_size",
-                "log_n", "shard_w", "shard_h", "devices", "shard_mode", "peer_access"]
+                "log_n", "shard_w", "shard_h", "devices", "shard_mode", "peer_access", "fixed_tables"]
         d = dict(zip(keys, list(out)))
         d["shard_mode"] = {0: "none", 1: "points", 2: "buckets"}.get(d["shard_mode"], "?")
         return d

@@ -56,7 +56,7 @@ class KeyDesc(C.Structure):
 class Options(C.Structure):
     _fields_ = [("device", C.c_int), ("rank", C.c_int), ("world", C.c_int),
                 ("window_bits", C.c_int), ("planes", C.c_int), ("dist_wm", C.c_int),
-                ("reduction", C.c_int), ("shard", C.c_int)]
+                ("reduction", C.c_int), ("shard", C.c_int), ("fixed_tables", C.c_int)]
 
 
 SHARD_AUTO, SHARD_POINTS, SHARD_BUCKETS = 0, 1, 2

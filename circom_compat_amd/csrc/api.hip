@@ -319,8 +319,47 @@ namespace g16 {
 
 void rank_collect_times(g16_ctx* c) { collect_times(c); }
 
+// Small keys: the same proof through the fixed-base tables (msm_table.h).  Main stream: the five
+// witness-scalar G1 sums (A, B1, L, s A, r B1); aux: witness map -> H; red: B2; side: the (r, s)-only
+// fixed-base sums; then the finalisation the sharded provers use (no variable-base product left).
+static void enqueue_prove_tables(g16_ctx* c, const Fr* w_dev) {
+  hipStream_t s = c->stream;
+  hipStream_t x = c->overlap ? c->aux : s, q = c->overlap ? c->red : s, sd = c->overlap ? c->side : s;
+  StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
+  ProofSums* S = c->sums_dev.p;
+  G16_HIP(hipMemcpyAsync(c->rs_dev.p, c->pin_io, 64, hipMemcpyHostToDevice, s));
+  G16_HIP(hipEventRecord(c->ev_start, s));  // (r, s) and the witness are resident
+  G16_HIP(hipStreamWaitEvent(sd, c->ev_start, 0));
+  fin_fixed_dist(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, sd);
+  G16_HIP(hipEventRecord(c->ev_fixed, sd));
+  G16_HIP(hipStreamWaitEvent(x, c->ev_start, 0));
+  int id = tm ? tm->begin(ST_WITNESS_MAP, x) : -1;
+  c->wm.run(w_dev, c->h_canon.p, nullptr, x);
+  if (tm) tm->end(id, x);
+  id = tm ? tm->begin(ST_MSM_TABLE_G1, x) : -1;
+  c->tbl.run_h(c->h_canon.p, S, x);
+  if (tm) tm->end(id, x);
+  G16_HIP(hipEventRecord(c->ev_h, x));
+  G16_HIP(hipStreamWaitEvent(q, c->ev_start, 0));
+  id = tm ? tm->begin(ST_MSM_TABLE_G2, q) : -1;
+  c->tbl.run_g2_witness(w_dev + 1, S, q);
+  if (tm) tm->end(id, q);
+  G16_HIP(hipEventRecord(c->ev_b2, q));
+  id = tm ? tm->begin(ST_MSM_TABLE_G1, s) : -1;
+  c->tbl.run_g1_witness(w_dev + 1, c->rs_dev.p, S, s);
+  if (tm) tm->end(id, s);
+  G16_HIP(hipStreamWaitEvent(s, c->ev_h, 0));
+  G16_HIP(hipStreamWaitEvent(s, c->ev_b2, 0));
+  G16_HIP(hipStreamWaitEvent(s, c->ev_fixed, 0));
+  id = tm ? tm->begin(ST_FINALIZE, s) : -1;
+  fin_final_dist(c->key_dev.p, S, c->fin_scr.p, c->out_dev.p, s);
+  if (tm) tm->end(id, s);
+  G16_HIP(hipMemcpyAsync(c->pin_io + 64, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
+}
+
 // one whole single-device proof, enqueue only: (r, s) from and the proof to the ctx's pinned buffer
 static void enqueue_prove(g16_ctx* c, const Fr* w_dev) {
+  if (c->tbl.active) return enqueue_prove_tables(c, w_dev);
   hipStream_t s = c->stream;
   G16_HIP(hipMemcpyAsync(c->rs_dev.p, c->pin_io, 64, hipMemcpyHostToDevice, s));
   // fork: the (r, s)-only part of the finalisation runs beside the witness map / MSMs
@@ -657,6 +696,29 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       G16_HIP(hipStreamSynchronize(s));  // `mine` is read by the async upload
     } else {
       c->ptsH.init((const G1Affine*)key->h_query + c->h_lo, lh, c->cfg_h, s);
+    }
+
+    // Small keys (g16_options.fixed_tables): fixed-base tables, the path g16_prove takes when they
+    // exist; the planes / sorts above stay for the single-MSM entry points and cost nothing at this size.
+    {
+      const bool can = c->world == 1 && !c->dist_wm && c->has_key;
+      if (o.fixed_tables > 0 && !can)
+        throw std::runtime_error("fixed_tables: only a single-device proving ctx (world = 1, no distributed witness map) can use them");
+      if (lender && lend_h) {
+        if (lender->tbl.active && o.fixed_tables >= 0) c->tbl.borrow(lender->tbl);
+        else if (o.fixed_tables > 0) throw std::runtime_error("fixed_tables: the donor has no tables to lend");
+      } else if (can && !lender && o.fixed_tables >= 0) {
+        const size_t need = tbl_bytes((size_t)2 * lw + l_cnt + lh, lw);
+        size_t fr = 0, tot = 0;
+        G16_HIP(hipMemGetInfo(&fr, &tot));
+        const bool fits = need <= fr / 3;
+        const bool small = lw <= TBL_MAX_POINTS && lh <= TBL_MAX_POINTS;
+        if (o.fixed_tables > 0 && !fits)
+          throw std::runtime_error("fixed_tables: the tables need " + std::to_string(need >> 20) + " MiB, more than a third of the free device memory");
+        if (o.fixed_tables > 0 || (small && fits))
+          c->tbl.build(key->a_query + 64, key->b_g1_query + 64, key->b_g2_query + 128,
+                       key->l_query + (size_t)(l_first - c->p) * 64, key->h_query, lw, l_first - c->w_lo, l_cnt, lh, s);
+      }
     }
 
     // workspaces: G1 over the witness sort (3 slots when the reductions are batched), G1 over the h
@@ -1116,7 +1178,7 @@ g16_status g16_stage_times(g16_ctx* c, float ms[G16_N_STAGES], uint32_t launches
 const char* g16_stage_name(int stage) {
   static const char* names[ST_COUNT] = {"witness_map",       "msm_sort",   "msm_accumulate_g1",
                                         "msm_accumulate_g2", "msm_reduce", "finalize",
-                                        "msm_accumulate_g1_pair", "msm_fixup"};
+                                        "msm_accumulate_g1_pair", "msm_fixup", "msm_table_g1", "msm_table_g2"};
   return (stage >= 0 && stage < ST_COUNT) ? names[stage] : "?";
 }
 
@@ -1137,6 +1199,7 @@ g16_status g16_ctx_info(const g16_ctx* c, uint32_t out[16]) {
   out[10] = c->w_hi - c->w_lo;
   out[11] = c->h_hi - c->h_lo;
   out[13] = c->world > 1 ? (c->shard_buckets ? G16_SHARD_BUCKETS : G16_SHARD_POINTS) : 0;
+  out[15] = c->tbl.active ? 1u : 0u;
   return G16_OK;
 }
 

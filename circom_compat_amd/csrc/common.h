@@ -82,6 +82,8 @@ enum Stage {
   ST_FINALIZE,
   ST_MSM_ACC_G1_PAIR,  // k_bucket_accumulate<Fq, 2, true>: A and B1 in one launch (interleaved pair)
   ST_MSM_FIXUP,        // k_acc_fixup + the exact kernel behind an optimistic G1 launch (early exit unless the list overflowed)
+  ST_MSM_TABLE_G1,     // small keys: k_tbl_msm<Fq> + k_tbl_final (fixed-base tables, msm_table.h)
+  ST_MSM_TABLE_G2,
   ST_COUNT
 };
 

@@ -8,6 +8,7 @@
 #include <string>
 
 #include "finalize.h"
+#include "msm_table.h"
 #include "msm.h"
 #include "witness_map.h"
 #include "wm_dist.h"
@@ -63,6 +64,7 @@ struct g16_ctx {
   g16::MsmPoints<g16::Fq2> ptsB2;
   g16::MsmWork<g16::Fq> work1, workH;  // witness-scalar G1 MSMs (A, B1, L) / H MSM
   g16::MsmWork<g16::Fq2> work2;
+  g16::TableSet tbl;  // small keys: fixed-base tables (msm_table.h); g16_prove goes through them when active
 
   g16::DevBuf<g16::Fr> w_dev, h_dev, rs_dev;  // h_dev: storage form (g16_witness_map / g16_msm_g1 staging)
   g16::DevBuf<g16::U256> h_canon;             // h as canonical integers: scalars of the H-query MSM

@@ -77,6 +77,13 @@ typedef struct {
                       itself: what a one-process run of the host framework's collectives drives)      */
   int reduction;   /* G16_REDUCTION_CIRCOM (0, default) or G16_REDUCTION_LIBSNARK                  */
   int shard;       /* world > 1: G16_SHARD_AUTO (0), G16_SHARD_POINTS, G16_SHARD_BUCKETS (below)    */
+  int fixed_tables; /* small keys: every MSM of g16_prove as table lookups + a tree sum (per point and
+                      8-bit window the multiples 1..128: 256 KiB per G1 point, 512 KiB per G2 point) and
+                      the finalisation's variable-base products as two more table MSMs -- ~20 launches
+                      with ~21 dependent EC additions each instead of ~75 with bucket reductions.
+                      0: automatic (single-device proving ctx, <= 2^14 points per query, tables within a
+                      third of the free device memory); > 0: require it (creation fails where it cannot
+                      apply); < 0: never.  Results are the same group elements either way.            */
 } g16_options;
 
 /* How the MSMs of one proof are cut over `world` ranks:
@@ -236,7 +243,7 @@ g16_status g16_prove_dist_phase3(g16_ctx* ctx, const void* recv_dev,
                                  uint8_t partial_out[G16_PARTIAL_BYTES]);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
-#define G16_N_STAGES 8
+#define G16_N_STAGES 10
 g16_status g16_set_profiling(g16_ctx* ctx, int enabled);
 /* HIP-event times accumulated since the last call; resets the accumulators.  Stages, in order:
  * witness_map, msm_sort, msm_accumulate_g1 (L, H), msm_accumulate_g2 (B2), msm_reduce, finalize,

@@ -15,7 +15,7 @@ pub const G16_ERR_INTERNAL: g16_status = 6;
 
 pub const G16_PROOF_BYTES: usize = 256;
 pub const G16_PARTIAL_BYTES: usize = 1024;
-pub const G16_N_STAGES: usize = 8;
+pub const G16_N_STAGES: usize = 10;
 pub const G16_SHARD_AUTO: c_int = 0;
 pub const G16_SHARD_POINTS: c_int = 1;
 pub const G16_SHARD_BUCKETS: c_int = 2;
@@ -82,6 +82,8 @@ pub struct g16_options {
     pub reduction: c_int,
     /// world > 1 / multi-device: G16_SHARD_AUTO, G16_SHARD_POINTS or G16_SHARD_BUCKETS
     pub shard: c_int,
+    /// small keys: 0 = automatic fixed-base tables, > 0 require, < 0 never (include/g16_amd.h)
+    pub fixed_tables: c_int,
 }
 
 #[repr(C)]

@@ -52,13 +52,13 @@ for i in (3, 4, 5):
         want = cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
         cpu_ms = (time.perf_counter() - t) * 1e3
         info = pr.info()
-        rows.append(dict(variables=V, constraints=Cn, domain=info["domain_size"], c_w=info["c_w"], gpu_ms=gpu_ms,
+        rows.append(dict(variables=V, constraints=Cn, domain=info["domain_size"], c_w=info["c_w"], fixed_tables=info["fixed_tables"], gpu_ms=gpu_ms,
                          gpu_ms_witness_from_host=gpu_host_ms, cpu_ms=cpu_ms, bytes_equal=bool(proof.raw == want)))
         pr.close()
-print("| variables | constraints | domain | window c | GPU ms (witness in HBM) | GPU ms (witness from host) | CPU restatement ms | proofs byte-equal |")
-print("|---|---|---|---|---|---|---|---|")
+print("| variables | constraints | domain | window c | fixed-base tables | GPU ms (witness in HBM) | GPU ms (witness from host) | CPU restatement ms | proofs byte-equal |")
+print("|---|---|---|---|---|---|---|---|---|")
 for r in rows:
-    print(f"| {r['variables']} | {r['constraints']} | {r['domain']} | {r['c_w']} | {r['gpu_ms']:.2f} | {r['gpu_ms_witness_from_host']:.2f} | "
+    print(f"| {r['variables']} | {r['constraints']} | {r['domain']} | {r['c_w']} | {'yes' if r['fixed_tables'] else 'no'} | {r['gpu_ms']:.2f} | {r['gpu_ms_witness_from_host']:.2f} | "
           f"{r['cpu_ms']:.0f} | {r['bytes_equal']} |")
 print()
 print(json.dumps({"reps": reps, "cpu_threads": cpu_ref.max_threads(), "cpu_variant": cpu_ref.variant(), "rows": rows}))

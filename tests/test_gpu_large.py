@@ -800,3 +800,66 @@ def test_rccl_executes_next_to_the_library_world1(gpulib, tmp_path):
                        timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "rccl backend: nccl ok" in r.stdout
+
+
+@pytest.mark.parametrize("logm", [10, 13, 14])
+def test_fixed_base_tables_prover_vs_cpu_restatement(gpulib, logm):
+    """Small keys through the fixed-base tables (g16_options.fixed_tables; csrc/msm_table.hip) on the real
+    kernels: squaring chains of 2^10 / 2^13 / 2^14 rows (the last one = the automatic rule's limit: 4 GiB
+    per G1 query, 8 GiB for B2), key minted on the GPU.  `tables=0` (the library's default) selects the
+    path; proof bytes == the CPU restatement's == the bucket path's (`tables=-1`), two (r, s) pairs;
+    pairing accepted, wrong input rejected."""
+    import circom_compat_amd as cc
+    import cpu_ref
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    mats, (A, B, Cm), w_ints, n_vars = bench.chain_circuit(cc, logm)
+    rng = random.Random(600 + logm)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox)
+    w = cc.fr_from_ints(w_ints)
+    tab = cc.Prover(pk, mats, tables=0)
+    assert tab.info()["fixed_tables"] == 1
+    buck = cc.Prover(pk, mats, tables=-1)
+    assert buck.info()["fixed_tables"] == 0
+    for _ in range(2):
+        rs = cc.fr_from_ints([rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)])
+        want = cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
+        proof = tab.prove(rs[0], rs[1], w)
+        assert proof.raw == want
+        assert buck.prove(rs[0], rs[1], w).raw == want
+    assert o.verify_proof(_vk_dict(pk), [w_ints[1]], H.proof_from_bytes(proof.raw))
+    assert not o.verify_proof(_vk_dict(pk), [(w_ints[1] + 1) % o.R_MOD], H.proof_from_bytes(proof.raw))
+    tab.close()
+    buck.close()
+
+
+def test_fixed_base_tables_reference_bench_circuit_and_limits(gpulib):
+    """The reference bench's own circuit (complex-circuit-10000-10000.r1cs, benches/groth16.rs:106) takes the
+    table path by default: bytes == the CPU restatement's, the proof verifies.  One size above the
+    automatic limit (2^15 wires) the default stays on the bucket path; `tables=1` on a sharded ctx is an
+    error that says why."""
+    import circom_compat_amd as cc
+    import cpu_ref
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    mats, (A, B, Cm), w_ints, n_vars = bench.complex_circuit(cc)
+    rng = random.Random(77)
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    pk = cc.trapdoor_setup(A, B, Cm, n_vars, 1, tox)
+    w = cc.fr_from_ints(w_ints)
+    pr = cc.Prover(pk, mats, tables=0)
+    assert pr.info()["fixed_tables"] == 1
+    rs = cc.fr_from_ints([rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)])
+    proof = pr.prove(rs[0], rs[1], w)
+    assert proof.raw == cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
+    assert o.verify_proof(_vk_dict(pk), [w_ints[1]], H.proof_from_bytes(proof.raw))
+    with pytest.raises(cc.G16Error) as e:
+        cc.Prover(pk, mats, devices=[0, 0], tables=1)
+    assert "fixed_tables" in str(e.value)
+    pr.close()
+    mats2, (A2, B2, C2), w2, nv2 = bench.chain_circuit(cc, 15)
+    pk2 = cc.trapdoor_setup(A2, B2, C2, nv2, 1, tox)
+    big = cc.Prover(pk2, mats2, tables=0)
+    assert big.info()["fixed_tables"] == 0
+    big.close()

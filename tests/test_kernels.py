@@ -920,6 +920,81 @@ def test_donor_destroyed_before_its_sibling_keeps_the_planes_alive(lib):
     d2.close()
 
 
+def test_fixed_base_tables_prover_test_zkey(lib, golden):
+    """Small keys prove through fixed-base tables (g16_options.fixed_tables, csrc/msm_table.hip): every
+    MSM of create_proof_with_assignment as table lookups + a tree sum, s*A and r*B1 as two more table
+    MSMs.  On the reference's own zkey: proof bytes == the oracle's for the KAT (r, s), for r = s = 0
+    (no blinding: the fixed-base sums are all empty) and r != 0 = s; `tables=0` (automatic) selects the
+    path for a key this small, `tables=-1` never does and gives the same bytes; a sibling borrows the
+    tables, and survives its donor."""
+    import circom_compat_amd as cc
+    pk, mats = cc.read_zkey(os.path.join(golden, "test.zkey"), lib=lib)
+    opk, omats = o.read_zkey(open(os.path.join(golden, "test.zkey"), "rb").read())
+    w = [1, 33, 3, 11]
+    pr = cc.Prover(pk, mats, lib=lib, tables=1)
+    assert pr.info()["fixed_tables"] == 1
+    auto = cc.Prover(pk, mats, lib=lib, tables=0)
+    assert auto.info()["fixed_tables"] == 1
+    never = cc.Prover(pk, mats, lib=lib, tables=-1)
+    assert never.info()["fixed_tables"] == 0
+    sib = cc.Prover(pk, mats, lib=lib, sibling_of=pr, tables=0)
+    assert sib.info()["fixed_tables"] == 1
+    rs = [(3413513218498352040262653353725127729454431939539290118844322056224532443637,
+           6077776500692565155461894309070795882353485867345896979329447163197530625403), (0, 0), (5, 0),
+          (o.R_MOD - 1, o.R_MOD - 1)]
+    for r, s in rs:
+        want = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, r, s, omats, 2, 1, w))
+        assert pr.prove(r, s, w).raw == want
+        assert never.prove(r, s, w).raw == want
+        assert sib.prove(r, s, w).raw == want
+    assert auto.prove(*rs[0], w).raw == pr.prove(*rs[0], w).raw
+    sib._donor = None
+    pr.close()
+    want = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, 7, 9, omats, 2, 1, w))
+    assert sib.prove(7, 9, w).raw == want
+    # a wrong witness length is still an error on this path, and the proof of a wrong witness does not verify
+    with pytest.raises(cc.G16Error):
+        auto.prove(1, 2, w + [5])
+    bad = auto.prove(1, 2, [1, 34, 3, 11])
+    assert not o.verify_proof(opk, [34], H.proof_from_bytes(bad.raw))
+    assert o.verify_proof(opk, [33], H.proof_from_bytes(auto.prove(1, 2, w).raw))
+
+
+@pytest.mark.parametrize("case", ["chain", "public-inputs", "infinity-points", "libsnark"])
+def test_fixed_base_tables_prover_circuits(lib, golden, case):
+    """The table path on circuits with more than one row: a squaring chain (multi-element NTT domain),
+    several public inputs (the L query starts at wire p + 1), a dense circuit whose witness is full of
+    0 / 1 scalars and whose B queries hold points at infinity (table rows of zeros), and
+    LibsnarkReduction on the reference's mycircuit.r1cs (H query padded with infinity): bytes == the
+    Python oracle's, scalars 0, 1, r - 1 and full-width among them."""
+    import circom_compat_amd as cc
+    rng = random.Random(len(case) * 7919)
+    red = "circom"
+    if case == "chain":
+        cons, w, n_vars, n_pub = H.squaring_chain(3)
+    elif case == "public-inputs":
+        cons, w, n_vars, _ = H.dense_skewed_circuit(7, seed=3, long_rows=())
+        n_pub = 3
+    elif case == "infinity-points":
+        cons, w, n_vars, n_pub = H.dense_skewed_circuit(10, seed=4, long_rows=(5,))
+        w = list(w)
+    else:
+        r1, w = _fixture(golden, "mycircuit")
+        cons, n_vars, n_pub, red = r1["constraints"], r1["n_wires"], r1["num_inputs"] - 1, "libsnark"
+    tox = [rng.randrange(1, o.R_MOD) for _ in range(5)]
+    opk = o.trapdoor_setup(cons, n_vars, n_pub, *tox, reduction=red)
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, n_pub + 1, n_vars, lib)
+    pk = H.pk_from_oracle(opk)
+    pr = cc.Prover(pk, mats, lib=lib, tables=1, reduction=red)
+    assert pr.info()["fixed_tables"] == 1
+    for r, s in ((rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)), (1, o.R_MOD - 1)):
+        want = o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), n_pub + 1, len(cons), w,
+                                                          reduction=red)
+        assert pr.prove(r, s, w).raw == o.proof_to_bytes(want)
+    pr.close()
+
+
 def test_sibling_ctx_shares_planes_two_proofs_in_flight(lib, golden):
     """g16_ctx_create_sibling: a second prover over the same key that borrows the donor's point planes.
     Both give the oracle's bytes -- alternately and from two host threads at once (the throughput mode
