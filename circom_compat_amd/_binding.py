@@ -17,7 +17,7 @@ G16_OK, G16_ERR_INVALID, G16_ERR_DOMAIN_TOO_LARGE, G16_ERR_HIP, G16_ERR_NO_DEVIC
     G16_ERR_INTERNAL = range(7)
 G16_PROOF_BYTES = 256
 G16_PARTIAL_BYTES = 1024
-G16_N_STAGES = 8
+G16_N_STAGES = 10
 QUERY_A, QUERY_B1, QUERY_L, QUERY_H = 0, 1, 2, 3
 
 _u8p = C.POINTER(C.c_uint8)

@@ -6,6 +6,7 @@
 #include <stddef.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "ctx.h"
@@ -92,8 +93,10 @@ void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_
   if (o.planes > 0) return;  // the caller's choice: allocation failures are reported as such
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) return;
-  const size_t margin = ((size_t)2 << 30) + fr / 50;
-  const size_t budget = fr > margin ? fr - margin : 0;
+  // margin: 2 GiB + 2 % on a device with room, never more than a quarter of what is free (a box whose
+  // memory is mostly taken -- the host framework's caching allocator, other ctxs -- still serves a small key)
+  const size_t margin = std::min(((size_t)2 << 30) + fr / 50, fr / 4);
+  const size_t budget = fr - margin;
   if (msm_state_bytes(*cw, *ch, lw, l_cnt, lh, wr, sharded, own_w, own_h) <= budget) return;  // full planes fit
   // the distinct (D, Pn) layouts of each side, most planes first
   auto layouts = [&](const MsmConfig& full, uint32_t len, bool own) {
@@ -119,8 +122,13 @@ void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_
         *ch = b;
       }
     }
-  if (best < 0)
-    throw std::runtime_error("the proving key does not fit this device's memory even with one plane per point");
+  if (best < 0) {
+    if (!own_w && !own_h)  // a borrower owns no planes: what does not fit is its own sort / workspace state
+      throw std::runtime_error("the sort and partial-sum state of this ctx does not fit the device memory that is free (" +
+                               std::to_string(fr >> 20) + " MiB)");
+    throw std::runtime_error("the proving key does not fit this device's memory even with one plane per point (" +
+                             std::to_string(fr >> 20) + " MiB free)");
+  }
 }
 
 void collect_times(g16_ctx* c) {
@@ -164,15 +172,11 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   ProofSums* S = c->sums_dev.p;
   if (!sorted) enqueue_witness_sort(c, w_dev);
-  // G16_REDUCE_OFF_MAIN = 0 | 1 (measurement only) overrides the size rule of the schedule below; read
-  // per proof, not once per process: scripts/dist_projection.py sweeps it over one resident key
-  auto env_int = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; };
   // buckets this ctx reduces per MSM: 1/world of the set under bucket-range sharding
   const uint32_t nb_eff = c->cfg_w.nb() / (c->shard_buckets ? (uint32_t)c->world : 1u);
   const bool small = nb_eff < (1u << 18);
   const uint32_t b2_limit = c->world > 1 ? (1u << 18) : (1u << 16);
   const bool b2_off = c->overlap && nb_eff < b2_limit;
-  const int knob_off = env_int("G16_REDUCE_OFF_MAIN");
   // Sharded ranks (either cut): the reductions always leave the main stream, whatever the size of the
   // bucket set.  A rank's chip is kept full by the distributed witness map on the aux stream, so a
   // reduction on the main stream is exposed latency there while its work costs the same issue slots
@@ -181,7 +185,7 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
   // one batched reduction of A, B1, L instead: 22.0 ms.
   const bool sharded = c->world > 1 || c->dist_wm;
   const bool mid = (nb_eff >= (1u << 15) && small) || (sharded && nb_eff >= (1u << 15));
-  if ((knob_off < 0 ? mid : knob_off != 0) && c->overlap && c->work1.batch >= 3) {
+  if (mid && c->overlap && c->work1.batch >= 3) {
     // Mid-sized bucket sets (2^15..2^17: 2^18..2^20-constraint proofs, ranks of a sharded 2^22
     // one): every reduction is a latency-bound chain long enough to matter and short enough to
     // hide, so none stays on the main stream -- it only accumulates (A, B1, B2, L, then H) and the
@@ -324,37 +328,56 @@ void rank_collect_times(g16_ctx* c) { collect_times(c); }
 // fixed-base sums; then the finalisation the sharded provers use (no variable-base product left).
 static void enqueue_prove_tables(g16_ctx* c, const Fr* w_dev) {
   hipStream_t s = c->stream;
-  hipStream_t x = c->overlap ? c->aux : s, q = c->overlap ? c->red : s, sd = c->overlap ? c->side : s;
+  // q carries the G2 sum -- the longest dependent chain of the proof (Fq2 additions) -- on the ctx's
+  // HIGH-priority stream (aux), so that its workgroups are placed before the G1 launches' when the chip
+  // is full; the witness map -> H chain takes the red stream here
+  hipStream_t x = c->overlap ? c->red : s, q = c->overlap ? c->aux : s, sd = c->overlap ? c->side : s;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
   ProofSums* S = c->sums_dev.p;
   G16_HIP(hipMemcpyAsync(c->rs_dev.p, c->pin_io, 64, hipMemcpyHostToDevice, s));
   G16_HIP(hipEventRecord(c->ev_start, s));  // (r, s) and the witness are resident
-  G16_HIP(hipStreamWaitEvent(sd, c->ev_start, 0));
-  fin_fixed_dist(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, sd);
-  G16_HIP(hipEventRecord(c->ev_fixed, sd));
+  // the G2 sum first
+  G16_HIP(hipStreamWaitEvent(q, c->ev_start, 0));
+  int id = tm ? tm->begin(ST_MSM_TABLE_G2, q) : -1;
+  c->tbl.run_g2_witness(w_dev + 1, S, q);
+  if (tm) tm->end(id, q);
+  // witness map, then the H sum
   G16_HIP(hipStreamWaitEvent(x, c->ev_start, 0));
-  int id = tm ? tm->begin(ST_WITNESS_MAP, x) : -1;
+  id = tm ? tm->begin(ST_WITNESS_MAP, x) : -1;
   c->wm.run(w_dev, c->h_canon.p, nullptr, x);
   if (tm) tm->end(id, x);
   id = tm ? tm->begin(ST_MSM_TABLE_G1, x) : -1;
   c->tbl.run_h(c->h_canon.p, S, x);
   if (tm) tm->end(id, x);
   G16_HIP(hipEventRecord(c->ev_h, x));
-  G16_HIP(hipStreamWaitEvent(q, c->ev_start, 0));
-  id = tm ? tm->begin(ST_MSM_TABLE_G2, q) : -1;
-  c->tbl.run_g2_witness(w_dev + 1, S, q);
-  if (tm) tm->end(id, q);
+  // side: the (r, s)-only fixed-base sums and what can be added up front
+  G16_HIP(hipStreamWaitEvent(sd, c->ev_start, 0));
+  fin_fixed_dist(c->fin_tab.p, c->rs_dev.p, c->fin_scr.p, sd);
+  fin_tab_pre(c->key_dev.p, c->fin_scr.p, sd);
+  G16_HIP(hipEventRecord(c->ev_fixed, sd));
+  // behind the G2 sum: B = b' + MSM_B2
+  G16_HIP(hipStreamWaitEvent(q, c->ev_fixed, 0));
+  fin_tab_b(S, c->fin_scr.p, c->part_dev(), q);
   G16_HIP(hipEventRecord(c->ev_b2, q));
+  // main: the five witness-scalar G1 sums, A, the H-free part of C; then C behind the H sum
   id = tm ? tm->begin(ST_MSM_TABLE_G1, s) : -1;
   c->tbl.run_g1_witness(w_dev + 1, c->rs_dev.p, S, s);
   if (tm) tm->end(id, s);
-  G16_HIP(hipStreamWaitEvent(s, c->ev_h, 0));
-  G16_HIP(hipStreamWaitEvent(s, c->ev_b2, 0));
   G16_HIP(hipStreamWaitEvent(s, c->ev_fixed, 0));
   id = tm ? tm->begin(ST_FINALIZE, s) : -1;
-  fin_final_dist(c->key_dev.p, S, c->fin_scr.p, c->out_dev.p, s);
+  fin_tab_ac(S, c->fin_scr.p, c->part_dev(), s);
+  G16_HIP(hipStreamWaitEvent(s, c->ev_h, 0));
+  fin_tab_c(S, c->fin_scr.p, c->part_dev(), s);
   if (tm) tm->end(id, s);
-  G16_HIP(hipMemcpyAsync(c->pin_io + 64, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
+  G16_HIP(hipStreamWaitEvent(s, c->ev_b2, 0));
+  // A, B, C in XYZZ form (the partial-record slot of out_dev is free on a world = 1 ctx); proof_from_pin() divides
+  G16_HIP(hipMemcpyAsync(c->pin_io + 64 + G16_PROOF_BYTES, c->part_dev(), FIN_PROJ_BYTES, hipMemcpyDeviceToHost, s));
+}
+
+// after the main stream is synchronised: the proof bytes of the last enqueue_prove
+static void proof_from_pin(g16_ctx* c, uint8_t* proof_out) {
+  if (c->tbl.active) fin_tab_host_affine(c->pin_io + 64 + G16_PROOF_BYTES, proof_out);
+  else memcpy(proof_out, c->pin_io + 64, G16_PROOF_BYTES);
 }
 
 // one whole single-device proof, enqueue only: (r, s) from and the proof to the ctx's pinned buffer
@@ -473,23 +496,6 @@ const char* g16_last_error(const g16_ctx* ctx) {
 
 namespace g16 {
 
-// Do the full planes of the four witness queries (+ H, counted whole as an upper bound) fit `device`?
-// Asked before a bucket-sharded ctx is built (G16_SHARD_BUCKETS), so that the refusal names the reason.
-bool bucket_shard_fits(int device, uint32_t n_vars, uint32_t domain, const g16_options* opt) {
-  if (hipSetDevice(device) != hipSuccess) return false;
-  size_t fr = 0, tot = 0;
-  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
-  const size_t len_w = n_vars > 1 ? n_vars - 1 : 1;
-  const MsmConfig cw = msm_make_config(len_w, opt ? opt->window_bits : 0, opt ? opt->planes : 0);
-  const MsmConfig ch = msm_make_config(domain ? domain : 1, opt ? opt->window_bits : 0, opt ? opt->planes : 0);
-  // planes (the H query stays point-sharded: counted whole, as an upper bound) + both sorts (8 + 4
-  // bytes per entry) + work buffers, against 70 % of what is free beyond 3 GiB
-  const size_t planes = (size_t)cw.Pn * len_w * (64 * 3 + 128) + (size_t)ch.Pn * domain * 64;
-  const size_t sorts = ((size_t)cw.W * len_w + (size_t)ch.W * domain) * 12;
-  const size_t work = ((size_t)cw.nb() + cw.max_lanes()) * (144 * 3 + 288) + ((size_t)ch.nb() + ch.max_lanes()) * 144;
-  const size_t reserve = (size_t)3 << 30;
-  return fr > reserve && planes + sorts + work < (size_t)((fr - reserve) * 0.7);
-}
 
 g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_csr* b,
                            uint32_t num_constraints, const g16_options* opt, g16_ctx* share_from,
@@ -596,8 +602,9 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     // digits and that front costs what the single-GPU window saves; point ranges need 1/world of the
     // key per device instead of all of it.  DESIGN.md section 7.
     c->shard_buckets = c->world > 1 && c->has_key && o.shard == G16_SHARD_BUCKETS;  // one rank: nothing to cut
-    if (c->shard_buckets && !share_from && !bucket_shard_fits(c->device, c->N, c->n, &o))
-      throw std::runtime_error("G16_SHARD_BUCKETS: the full point planes of the witness queries do not fit this device");
+    // (a bucket-sharded rank holds ALL points of the witness queries: plan_msm_configs below plans its
+    // planes like any other ctx's -- full when they fit, fewer otherwise -- round 4's separate pre-check
+    // refused keys the plan can serve)
     c->share_from = (c->shard_buckets || c->world == 1) ? share_from : nullptr;
     if (c->share_from) ++c->share_from->borrowers;
     // the H query is ALWAYS cut by point range: its scalars are born sharded (the distributed
@@ -634,7 +641,7 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     c->out_dev.alloc(G16_PROOF_BYTES + G16_PARTIAL_BYTES * (size_t)(c->world + 1));
     {
       void* pin = nullptr;
-      G16_HIP(hipHostMalloc(&pin, 64 + G16_PROOF_BYTES, 0));
+      G16_HIP(hipHostMalloc(&pin, 64 + G16_PROOF_BYTES + FIN_PROJ_BYTES, 0));
       c->pin_io = (uint8_t*)pin;
     }
 
@@ -966,7 +973,7 @@ g16_status g16_prove_dev(g16_ctx* c, const uint64_t r[4], const uint64_t s_[4], 
     memcpy(c->pin_io + 32, s_, 32);
     enqueue_prove(c, (const Fr*)w_dev);
     G16_HIP(hipStreamSynchronize(s));
-    memcpy(proof_out, c->pin_io + 64, G16_PROOF_BYTES);
+    proof_from_pin(c, proof_out);
     collect_times(c);
     return G16_OK;
   });

@@ -108,7 +108,6 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
                            uint32_t num_constraints, const g16_options* opt, g16_ctx* share_from,
                            g16_ctx** out, std::string* err);
 // true when the full-precomputation planes of the WHOLE key fit `device` (bucket-range sharding)
-bool bucket_shard_fits(int device, uint32_t n_vars, uint32_t domain, const g16_options* opt);
 void rank_partial_enqueue(g16_ctx* c, const uint64_t r[4], const uint64_t s[4], const Fr* w_dev);
 // gathered: world x G16_PARTIAL_BYTES already in c->gathered_dev() (ordered on the main stream)
 void rank_finish_enqueue(g16_ctx* c, const uint64_t r[4], const uint64_t s[4], int world);

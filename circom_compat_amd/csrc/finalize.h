@@ -69,6 +69,21 @@ void fin_partial_var(ProofSums* sums, const Fr* rs_dev, hipStream_t stream);  //
 void fin_fixed_dist(const FinTables* tab, const Fr* rs_dev, FinScratch* scr, hipStream_t stream);
 void fin_final_dist(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr,
                     uint8_t* proof_dev, hipStream_t stream);
+// ---- small keys through fixed-base tables (msm_table.h): the same equations in stages, each enqueued
+// behind the sums it needs, so that one addition + one affine conversion follow the LAST sum of A, B, C:
+//   fin_tab_pre  (after fin_fixed_dist)   a' = r delta1 + a0 + alpha1 (-> scr.sga), b' = s delta2 + b2_0 + beta2 (-> scr.sd2)
+//   fin_tab_ac   (after A, B1, L, sA, rB1) A = a' + MSM_A -> proj; c' = sA + rB1 + sta + rtb + rs delta1 + L (-> scr.rgb)
+//   fin_tab_c    (after H)                 C = c' + MSM_H -> proj
+//   fin_tab_b    (after B2)                B = b' + MSM_B2 -> proj
+// A, B, C leave the device in XYZZ form (storage Montgomery, FIN_PROJ_BYTES at proj_dev) and the host
+// divides (fin_tab_host_affine: three field inversions by binary Euclid, ~5 us each on a CPU core against
+// 150-250 us on one GPU lane; the host waits for these bytes anyway).  Same field elements, same bytes.
+constexpr int FIN_PROJ_A = 0, FIN_PROJ_B = 128, FIN_PROJ_C = 384, FIN_PROJ_BYTES = 512;
+void fin_tab_pre(const KeyHeaderDev* key, FinScratch* scr, hipStream_t stream);
+void fin_tab_ac(const ProofSums* sums, FinScratch* scr, uint8_t* proj_dev, hipStream_t stream);
+void fin_tab_c(const ProofSums* sums, const FinScratch* scr, uint8_t* proj_dev, hipStream_t stream);
+void fin_tab_b(const ProofSums* sums, const FinScratch* scr, uint8_t* proj_dev, hipStream_t stream);
+void fin_tab_host_affine(const uint8_t* proj_host, uint8_t* proof_out);  // host: FIN_PROJ_BYTES -> 256 proof bytes
 constexpr int FIN_PARTIAL_BYTES = 1024;  // A | B1 | B2 | L | H | sA | rB1 in XYZZ storage form (G1 128 B, G2 256 B)
 // ProofSums -> one rank's record (projective: no inversion before the all-gather)
 void sums_to_partial(const ProofSums* sums, uint8_t* partial_dev, hipStream_t stream);

@@ -337,6 +337,60 @@ __global__ void __launch_bounds__(64) k_fin_final_dist(const KeyHeaderDev* key, 
   }
 }
 
+// ---- small keys (fixed-base tables, msm_table.h): the tail in stages, so that ONE addition and one
+// affine conversion follow the last sum of each proof element ------------------------------------------
+// after fin_fixed_dist (side stream).  block 0: a' = r delta1 + a0 + alpha1 -> scr->sga;
+// block 1: b' = s delta2 + b2_0 + beta2 -> scr->sd2 (in place)
+__global__ void __launch_bounds__(64) k_fin_tab_pre(const KeyHeaderDev* key, FinScratch* scr) {
+  if (threadIdx.x != 0) return;
+  if (blockIdx.x == 0) {
+    G1XYZZ29 a = scr->rd1;
+    a.madd(affine_from_mont256<Fq>(key->a0));
+    a.madd(affine_from_mont256<Fq>(key->alpha1));
+    scr->sga = a;
+  } else {
+    G2XYZZ29 b = scr->sd2;
+    b.madd(affine_from_mont256<Fq2>(key->b2_0));
+    b.madd(affine_from_mont256<Fq2>(key->beta2));
+    scr->sd2 = b;
+  }
+}
+// The three results leave the device in XYZZ form (storage Montgomery): the one field inversion each
+// needs is ~150-250 us on one GPU lane and ~5 us on the host (fin_tab_host_affine), and the host waits for
+// these bytes anyway.
+// after the witness-scalar G1 sums (main stream).  block 0: A = a' + MSM_A -> proj;
+// block 1: c' = s A + r B1 + s (a0 + alpha1) + r (b1_0 + beta1) + rs delta1 + L -> scr->rgb
+__global__ void __launch_bounds__(64) k_fin_tab_ac(const ProofSums* sums, FinScratch* scr, uint8_t* proj) {
+  if (threadIdx.x != 0) return;
+  if (blockIdx.x == 0) {
+    G1XYZZ29 a = scr->sga;
+    a.add(sums->A);
+    *reinterpret_cast<XYZZ<Fq>*>(proj + FIN_PROJ_A) = xyzz_to_mont256<Fq>(a);
+  } else {
+    G1XYZZ29 c = sums->sA;
+    c.add(sums->rB1);
+    c.add(scr->sta);
+    c.add(scr->rtb);
+    c.add(scr->rsd1);
+    c.add(sums->L);
+    scr->rgb = c;
+  }
+}
+// after the H sum: C = c' + MSM_H -> proof
+__global__ void __launch_bounds__(64) k_fin_tab_c(const ProofSums* sums, const FinScratch* scr, uint8_t* proj) {
+  if (threadIdx.x != 0) return;
+  G1XYZZ29 c = scr->rgb;
+  c.add(sums->H);
+  *reinterpret_cast<XYZZ<Fq>*>(proj + FIN_PROJ_C) = xyzz_to_mont256<Fq>(c);
+}
+// after the B2 sum: B = b' + MSM_B2 -> proof
+__global__ void __launch_bounds__(64) k_fin_tab_b(const ProofSums* sums, const FinScratch* scr, uint8_t* proj) {
+  if (threadIdx.x != 0) return;
+  G2XYZZ29 b = scr->sd2;
+  b.add(sums->B2);
+  *reinterpret_cast<XYZZ<Fq2>*>(proj + FIN_PROJ_B) = xyzz_to_mont256<Fq2>(b);
+}
+
 __device__ __forceinline__ G1XYZZ29* g1_sum_slot(ProofSums* s, int b) {
   switch (b) {
     case 0: return &s->A;
@@ -457,6 +511,121 @@ void fin_fixed_dist(const FinTables* tab, const Fr* rs_dev, FinScratch* scr, hip
 void fin_final_dist(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr,
                     uint8_t* proof_dev, hipStream_t stream) {
   G16_LAUNCH(k_fin_final_dist, 3, 64, 0, stream, key, sums, scr, proof_dev);
+}
+// ---- host side of the table path: x = X / ZZ, y = Y / ZZZ for the three proof elements ----------------
+namespace {
+struct U256h {
+  uint64_t v[4];
+};
+inline bool is_one(const U256h& a) { return a.v[0] == 1 && !(a.v[1] | a.v[2] | a.v[3]); }
+inline bool geq(const U256h& a, const U256h& b) {
+  for (int i = 3; i >= 0; --i)
+    if (a.v[i] != b.v[i]) return a.v[i] > b.v[i];
+  return true;
+}
+inline uint64_t sub_to(U256h& a, const U256h& b) {  // a -= b, returns the borrow
+  unsigned __int128 br = 0;
+  for (int i = 0; i < 4; ++i) {
+    const unsigned __int128 d = (unsigned __int128)a.v[i] - b.v[i] - (uint64_t)br;
+    a.v[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+  return (uint64_t)br;
+}
+inline uint64_t add_to(U256h& a, const U256h& b) {  // a += b, returns the carry
+  unsigned __int128 c = 0;
+  for (int i = 0; i < 4; ++i) {
+    c += (unsigned __int128)a.v[i] + b.v[i];
+    a.v[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  return (uint64_t)c;
+}
+inline void shr1(U256h& a, uint64_t top) {
+  for (int i = 0; i < 3; ++i) a.v[i] = (a.v[i] >> 1) | (a.v[i + 1] << 63);
+  a.v[3] = (a.v[3] >> 1) | (top << 63);
+}
+// z^-1 as a field element (Montgomery in, Montgomery out); 0 -> 0.  Binary extended Euclid on the stored
+// integer (Guide to ECC, Alg. 2.22) -- the same algorithm as f29_inv_vartime, on 64-bit host words.
+Fq host_inv(const Fq& z) {
+  U256h u, v, x1{{1, 0, 0, 0}}, x2{{0, 0, 0, 0}}, p;
+  for (int i = 0; i < 4; ++i) {
+    u.v[i] = (uint64_t)z.v[2 * i] | ((uint64_t)z.v[2 * i + 1] << 32);
+    p.v[i] = (uint64_t)FqParams::MOD[2 * i] | ((uint64_t)FqParams::MOD[2 * i + 1] << 32);
+  }
+  if (!(u.v[0] | u.v[1] | u.v[2] | u.v[3])) return Fq::zero();
+  v = p;
+  auto halve = [&](U256h& x) {  // x / 2 mod p
+    uint64_t top = 0;
+    if (x.v[0] & 1) top = add_to(x, p);
+    shr1(x, top);
+  };
+  auto sub_mod = [&](U256h& a, const U256h& b) {
+    if (sub_to(a, b)) add_to(a, p);
+  };
+  for (int guard = 0; guard < 2048 && !is_one(u) && !is_one(v); ++guard) {
+    while (!(u.v[0] & 1)) {
+      shr1(u, 0);
+      halve(x1);
+    }
+    while (!(v.v[0] & 1)) {
+      shr1(v, 0);
+      halve(x2);
+    }
+    if (geq(u, v)) {
+      sub_to(u, v);
+      sub_mod(x1, x2);
+    } else {
+      sub_to(v, u);
+      sub_mod(x2, x1);
+    }
+  }
+  const U256h& r = is_one(u) ? x1 : x2;  // I = (z R)^-1 as an integer
+  U256 c;
+  for (int i = 0; i < 4; ++i) {
+    c.v[2 * i] = (uint32_t)r.v[i];
+    c.v[2 * i + 1] = (uint32_t)(r.v[i] >> 32);
+  }
+  // from_canonical(I) has the value I = z^-1 / R; times the element of value R (representation R^2)
+  return Fq::from_canonical(c) * Fq::r2();
+}
+Fq2 host_inv(const Fq2& z) {
+  const Fq n = host_inv(z.c0.sqr() + z.c1.sqr());
+  return Fq2{z.c0 * n, (z.c1 * n).neg()};
+}
+template <class F>
+Affine<F> host_affine(const XYZZ<F>& a) {
+  if (a.is_inf()) return Affine<F>::infinity();
+  const F iz3 = host_inv(a.zzz);
+  const F iz2 = iz3.sqr() * a.zz.sqr();  // 1 / zz = zz^2 / zzz^2
+  return Affine<F>{a.x * iz2, a.y * iz3};
+}
+}  // namespace
+
+void fin_tab_host_affine(const uint8_t* proj, uint8_t* proof) {
+  XYZZ<Fq> a, c;
+  XYZZ<Fq2> b;
+  memcpy((void*)&a, proj + FIN_PROJ_A, sizeof a);
+  memcpy((void*)&b, proj + FIN_PROJ_B, sizeof b);
+  memcpy((void*)&c, proj + FIN_PROJ_C, sizeof c);
+  const G1Affine pa = host_affine<Fq>(a), pc = host_affine<Fq>(c);
+  const G2Affine pb = host_affine<Fq2>(b);
+  memcpy(proof, (const void*)&pa, 64);
+  memcpy(proof + 64, (const void*)&pb, 128);
+  memcpy(proof + 192, (const void*)&pc, 64);
+}
+
+void fin_tab_pre(const KeyHeaderDev* key, FinScratch* scr, hipStream_t stream) {
+  G16_LAUNCH(k_fin_tab_pre, 2, 64, 0, stream, key, scr);
+}
+void fin_tab_ac(const ProofSums* sums, FinScratch* scr, uint8_t* proof_dev, hipStream_t stream) {
+  G16_LAUNCH(k_fin_tab_ac, 2, 64, 0, stream, sums, scr, proof_dev);
+}
+void fin_tab_c(const ProofSums* sums, const FinScratch* scr, uint8_t* proof_dev, hipStream_t stream) {
+  G16_LAUNCH(k_fin_tab_c, 1, 64, 0, stream, sums, scr, proof_dev);
+}
+void fin_tab_b(const ProofSums* sums, const FinScratch* scr, uint8_t* proof_dev, hipStream_t stream) {
+  G16_LAUNCH(k_fin_tab_b, 1, 64, 0, stream, sums, scr, proof_dev);
 }
 void sums_to_partial(const ProofSums* sums, uint8_t* partial_dev, hipStream_t stream) {
   G16_LAUNCH(k_sums_to_partial, 7, 64, 0, stream, const_cast<ProofSums*>(sums), partial_dev);

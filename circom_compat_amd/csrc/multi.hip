@@ -28,9 +28,9 @@
 #include <functional>
 #include <vector>
 
+#include <mutex>
 #ifndef G16_EMU
 #include <condition_variable>
-#include <mutex>
 #include <thread>
 #endif
 
@@ -460,6 +460,7 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
         lender[g] = f;
         break;
       }
+  std::mutex dev_mu[64];
   auto make_child = [&](int g) {
     g16_options o{};
     if (opt) o = *opt;
@@ -470,8 +471,14 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
     o.shard = M->buckets ? G16_SHARD_BUCKETS : G16_SHARD_POINTS;
     g16_ctx* c = nullptr;
     std::string cerr;
-    const g16_status s = ctx_create_impl(key, a, b, num_constraints, &o, lender[g] >= 0 ? M->ch[lender[g]] : nullptr,
-                                         &c, &cerr);
+    g16_status s;
+    {
+      // children that share a device ordinal (functional runs) are created one after the other: each plans
+      // its planes against the memory that is free at that moment (plan_msm_configs), and two planners
+      // reading the same figure would both commit it.  Distinct devices still build in parallel.
+      std::lock_guard<std::mutex> per_device(dev_mu[device_ids[g] & 63]);
+      s = ctx_create_impl(key, a, b, num_constraints, &o, lender[g] >= 0 ? M->ch[lender[g]] : nullptr, &c, &cerr);
+    }
     if (s != G16_OK)
       throw std::runtime_error("device " + std::to_string(device_ids[g]) + ": " + cerr +
                                (s == G16_ERR_DOMAIN_TOO_LARGE ? " PolynomialDegreeTooLarge" : ""));

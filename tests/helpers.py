@@ -108,8 +108,8 @@ def dense_skewed_circuit(m, seed=0, n_inputs=8, long_rows=()):
     for i in range(m):
         hi = len(w)
         if i in long_rows:
-            A = [(wi, rng.choice(coeffs)) for wi in distinct(min(65, hi - 2), list(range(2, hi)))]
-            B = [(wi, rng.choice(coeffs)) for wi in distinct(min(64, hi - 2), list(range(2, hi)))]
+            A = [(wi, rng.choice(coeffs)) for wi in distinct(min(65, hi - 2), range(2, hi))]
+            B = [(wi, rng.choice(coeffs)) for wi in distinct(min(64, hi - 2), range(2, hi))]
         elif rng.random() < 0.55:
             xi, xj, xk = distinct(3, bits)
             A = [(xi, 1), (xj, 1), (xk, R - 1)]                # in {-1, 0, 1, 2}
@@ -117,8 +117,8 @@ def dense_skewed_circuit(m, seed=0, n_inputs=8, long_rows=()):
             if rng.random() < 0.5:                             # 2-term B: bit * (1 - bit2) style
                 B = [(0, 1), (rng.choice(bits), R - 1)]
         else:
-            A = [(wi, rng.choice(coeffs)) for wi in distinct(3, list(range(2, hi)))]
-            B = [(wi, rng.choice(coeffs)) for wi in distinct(2, list(range(2, hi)))]
+            A = [(wi, rng.choice(coeffs)) for wi in distinct(3, range(2, hi))]  # a range, not a list: O(m) overall, same draws
+            B = [(wi, rng.choice(coeffs)) for wi in distinct(2, range(2, hi))]
         val = lc(A) * lc(B) % R
         w.append(val)
         if val in (0, 1):

@@ -265,16 +265,19 @@ def test_c_oracle_scalar_mul_matches_python_oracle():
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("logm", [12, 14] + [pytest.param(k, marks=pytest.mark.skipif(
-    not os.environ.get("G16_SLOW_PINS"), reason="opt-in (G16_SLOW_PINS=1): 1.5 / 7 min of pure-Python MSMs; "
-    "run once per round, log under profiles/")) for k in (16, 18)])
+@pytest.mark.parametrize("logm", [12, 14, 16] + [pytest.param(k, marks=pytest.mark.skipif(
+    not os.environ.get("G16_SLOW_PINS"), reason="opt-in (G16_SLOW_PINS=1): 1 / 5 min of pure-Python NTTs; "
+    "run once per round, log under profiles/")) for k in (18, 20)])
 def test_c_oracle_prove_matches_python_oracle_2p12_2p14(logm):
-    """oracle/groth16_cpu.c's CircomReduction prove == oracle/bn254_ref.py at 2^12 and 2^14 constraints
-    with uneven rows (dense-skewed family + one 9-term row): h element for element and the 256 proof
-    bytes.  This moves the byte-level pin of the C restatement -- the checker of every GPU proof at
-    2^14 .. 2^26 -- from 2^10 to 2^14 (MSM windows c = 10 / 11, 14-stage FFTs).  The key cycles through 64 random points
-    (prove is linear in the key: no trapdoor structure is needed, and 4096 x 6 Python scalar
-    multiplications would take minutes)."""
+    """oracle/groth16_cpu.c's CircomReduction prove == oracle/bn254_ref.py at 2^12, 2^14 and 2^16
+    constraints (default suite) and at 2^18 and 2^20 -- BASELINE configs[1]'s size -- (opt-in), with uneven
+    rows (dense-skewed family + one 9-term row): h element for element and the 256 proof bytes.  This is
+    the byte-level pin of the C restatement, the checker of every GPU proof at 2^14 .. 2^27.  The key
+    cycles through 64 random points (prove is linear in the key: no trapdoor structure is needed); since
+    round 5 the Python MSM adds the scalars of equal bases first (bn254_ref.Group.msm), so its cost at
+    these sizes is the six pure-Python NTTs: 12 s at 2^16, 1 min at 2^18, ~5 min at 2^20 (round 4: 11 min
+    at 2^18, most of it a quadratic list build in the circuit generator and a modular inversion per
+    converted element)."""
     import cpu_ref
     cons, wit, nv, _ = H.dense_skewed_circuit((1 << logm) - 5, seed=12, long_rows=(9,))
     npub, ni = 1, 2
