@@ -605,6 +605,16 @@ class Prover:
         return {self.lib.g16_stage_name(i).decode(): (float(ms[i]), int(cnt[i]))
                 for i in range(B.G16_N_STAGES)}
 
+    def links(self):
+        """multi-device ctx: the create-time link probe (g16_multi_links) as
+        {"probe_bytes", "gbps": [[src][dst]], "echo_us": [[src][dst]]}"""
+        n = self.info()["devices"]
+        gb, us = (C.c_float * (n * n))(), (C.c_float * (n * n))()
+        pb = C.c_uint64(0)
+        self.lib.check(self.lib.g16_multi_links(self.ctx, gb, us, n * n, C.byref(pb)), self.ctx)
+        return {"probe_bytes": int(pb.value), "gbps": [[float(gb[a * n + b]) for b in range(n)] for a in range(n)],
+                "echo_us": [[float(us[a * n + b]) for b in range(n)] for a in range(n)]}
+
     def info(self):
         out = (C.c_uint32 * 16)()
         self.lib.check(self.lib.g16_ctx_info(self.ctx, out), self.ctx)
@@ -612,6 +622,8 @@ class Prover:
                 "log_n", "shard_w", "shard_h", "devices", "shard_mode", "peer_access", "fixed_tables"]
         d = dict(zip(keys, list(out)))
         d["shard_mode"] = {0: "none", 1: "points", 2: "buckets"}.get(d["shard_mode"], "?")
+        d["sparse_b"] = (d["fixed_tables"] >> 1) & 1       # out[15]: bit 0 = fixed-base tables, bit 1 = filtered B view
+        d["fixed_tables"] &= 1
         return d
 
 

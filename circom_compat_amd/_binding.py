@@ -94,7 +94,7 @@ ABI_SYMBOLS = [
     "g16_ctx_create", "g16_ctx_create_sibling", "g16_ctx_destroy", "g16_last_error", "g16_witness_map", "g16_msm_g1",
     "g16_msm_g2", "g16_prove", "g16_prove_dev", "g16_prove_partial", "g16_prove_partial_dev",
     "g16_prove_finish", "g16_dist_exchange_bytes", "g16_prove_dist_phase1", "g16_prove_dist_phase2",
-    "g16_prove_dist_phase3", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info",
+    "g16_prove_dist_phase3", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info", "g16_multi_links",
     "g16_witness_buffer", "g16_witness_upload", "g16_witness_host_buffer", "g16_ctx_create_multi", "g16_dist_set_exchange_stream",
     "g16_partial_buffer", "g16_gather_buffer", "g16_prove_finish_dev", "g16_witness_map_dev", "g16_msm_g1_dev",
     "g16_msm_g2_dev", "g16_verify_batch", "g16_debug_ntt", "g16_debug_alu_bench", "g16_check_satisfied", "g16_zkey_write",
@@ -151,6 +151,7 @@ class Library:
             "g16_set_profiling": (C.c_int, [vp, C.c_int]),
             "g16_stage_times": (C.c_int, [vp, C.POINTER(C.c_float), _u32p]),
             "g16_stage_name": (C.c_char_p, [C.c_int]),
+            "g16_multi_links": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_uint64)]),
             "g16_ctx_info": (C.c_int, [vp, _u32p]),
             "g16_witness_buffer": (vp, [vp]),
             "g16_witness_host_buffer": (vp, [vp]),

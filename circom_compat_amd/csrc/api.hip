@@ -135,13 +135,16 @@ void collect_times(g16_ctx* c) {
   if (c->timer.enabled) c->timer.collect(c->st_ms, c->st_cnt);
 }
 
+void wait_for_b_view(g16_ctx* c, hipStream_t s);
+
 // A and B1 accumulations into work1 slots 0 and 1: one launch over the interleaved pair, or two
 void accumulate_ab(g16_ctx* c, hipStream_t s, StageTimer* tm, bool fixup = true) {
   if (c->ptsA.stride == 2) {
     msm_accumulate_pair<Fq>(c->sort_w, c->ptsA, c->ptsB1, c->work1, 0, s, tm, fixup);
   } else {
     msm_accumulate<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, s, tm, fixup);
-    msm_accumulate<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, s, tm, fixup);
+    wait_for_b_view(c, s);
+    msm_accumulate<Fq>(c->sort_for_b(), c->ptsB1, 0, c->work1, 1, s, tm, fixup);
   }
 }
 // the deferred exact additions of accumulate_ab(fixup = false), on the stream that reduces A and B1
@@ -151,8 +154,22 @@ void fixup_ab(g16_ctx* c, hipStream_t q) {
     msm_fixup_pair<Fq>(c->sort_w, c->ptsA, c->ptsB1, c->work1, 0, q, tm);
   } else {
     msm_fixup<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, q, tm);
-    msm_fixup<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, q, tm);
+    msm_fixup<Fq>(c->sort_for_b(), c->ptsB1, 0, c->work1, 1, q, tm);
   }
+}
+
+// bucket reductions of work1 slots 0 .. n - 1 (A, B1[, L]) into ProofSums (A, B1, L are adjacent there): ONE
+// batched launch over the witness sort -- unless B1 was accumulated over the filtered view (sparse B),
+// whose bucket offsets are its own
+void reduce_abl(g16_ctx* c, int n, hipStream_t q, StageTimer* tm, bool hidden) {
+  ProofSums* S = c->sums_dev.p;
+  if (!c->sparse_b) {
+    msm_reduce<Fq>(c->sort_w, c->work1, 0, n, &S->A, q, tm, hidden);
+    return;
+  }
+  msm_reduce<Fq>(c->sort_w, c->work1, 0, 1, &S->A, q, tm, hidden);
+  msm_reduce<Fq>(c->sort_b, c->work1, 1, 1, &S->B1, q, tm, hidden);
+  if (n == 3) msm_reduce<Fq>(c->sort_w, c->work1, 2, 1, &S->L, q, tm, hidden);
 }
 
 // main stream: witness-scalar sort, then the A, B1, L, B2 MSMs (ALU bound).  `after_ab` is called
@@ -164,6 +181,22 @@ void enqueue_witness_sort(g16_ctx* c, const Fr* w_dev) {
   int id = tm ? tm->begin(ST_MSM_SORT, s) : -1;
   c->sort_w.run(w_dev + 1 + c->w_lo, c->w_hi - c->w_lo, /*mont=*/true, s);
   if (tm) tm->end(id, s);
+  if (c->sparse_b) {
+    // the filtered view is built beside the A accumulation (which reads the full sort): on the `red`
+    // stream, B1 waits for ev_view (wait_for_b_view).  On the main stream it sat in front of everything:
+    // +1.1 ms at 2^20 (profiles/r05_sparse_b_ab.txt)
+    hipStream_t v = c->overlap ? c->red : s;
+    G16_HIP(hipEventRecord(c->ev_view, s));
+    G16_HIP(hipStreamWaitEvent(v, c->ev_view, 0));
+    id = tm ? tm->begin(ST_MSM_SORT, v) : -1;
+    c->sort_b.run_view(c->sort_w, c->keep_b, v);
+    if (tm) tm->end(id, v);
+    G16_HIP(hipEventRecord(c->ev_view, v));
+  }
+}
+// before the first launch that reads the filtered B view
+void wait_for_b_view(g16_ctx* c, hipStream_t s) {
+  if (c->sparse_b) G16_HIP(hipStreamWaitEvent(s, c->ev_view, 0));
 }
 
 template <class Hook, class Hook2>
@@ -205,12 +238,12 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     G16_HIP(hipEventRecord(c->ev_acc[0], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[0], 0));
     fixup_ab(c, q);
-    msm_reduce<Fq>(c->sort_w, c->work1, 0, 2, &S->A, q, tm, /*hidden=*/true);
+    reduce_abl(c, 2, q, tm, /*hidden=*/true);
     after_ab(q);
-    msm_accumulate<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, 0, s, tm);
+    msm_accumulate<Fq2>(c->sort_for_b(), c->ptsB2, 0, c->work2, 0, s, tm);
     G16_HIP(hipEventRecord(c->ev_acc[1], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[1], 0));
-    msm_reduce<Fq2>(c->sort_w, c->work2, 0, 1, &S->B2, q, tm, /*hidden=*/true);
+    msm_reduce<Fq2>(c->sort_for_b(), c->work2, 0, 1, &S->B2, q, tm, /*hidden=*/true);
     msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm, /*fixup=*/false);
     G16_HIP(hipEventRecord(c->ev_acc[2], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[2], 0));
@@ -229,14 +262,14 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     // share of a sharded 2^22 proof.  ProofSums keeps A, B1, L adjacent.
     accumulate_ab(c, s, tm);
     msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm);
-    msm_reduce<Fq>(c->sort_w, c->work1, 0, 3, &S->A, s, tm);
+    reduce_abl(c, 3, s, tm, false);
     after_ab(s);
   } else {
     // large bucket sets: the reduction is throughput bound, and reducing A and B1 at once lets
     // the variable-base part of the finalisation start ~10 ms earlier (measured at 2^22: 41.3 vs
     // 43.0 ms per proof)
     accumulate_ab(c, s, tm);
-    msm_reduce<Fq>(c->sort_w, c->work1, 0, 2, &S->A, s, tm);  // ProofSums keeps A, B1 adjacent
+    reduce_abl(c, 2, s, tm, false);  // ProofSums keeps A, B1 adjacent
     after_ab(s);
     // (round 4, VERDICT r3 item 5: taking the L reduction off the main stream -- beside the H
     // accumulation, or beside the H reduction -- was built and measured: 37.67 / 37.50 ms shipped vs
@@ -248,13 +281,13 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
   // slots from it.  Measured on one box, batched reduction / own stream for the B2 reduction:
   //   2^14: 4.60 ms neither, 3.84 batched, 3.64 both;  2^18: 6.74 / 5.61 / 5.23;
   //   2^20: 13.56 / 13.05 / 13.21;  2^22: 40.1 / 41.9 / -.   ev_side = "everything forked is done".
-  msm_accumulate<Fq2>(c->sort_w, c->ptsB2, 0, c->work2, 0, s, tm);
+  msm_accumulate<Fq2>(c->sort_for_b(), c->ptsB2, 0, c->work2, 0, s, tm);
   // sharded ranks: the main stream is the critical path (the witness-map phases and exchanges hide
   // under it), so the B2 reduction leaves it whenever the bucket set is small
   hipStream_t rs = b2_off ? c->red : s;
   G16_HIP(hipEventRecord(c->ev_b2, s));
   G16_HIP(hipStreamWaitEvent(rs, c->ev_b2, 0));
-  msm_reduce<Fq2>(c->sort_w, c->work2, 0, 1, &S->B2, rs, tm);
+  msm_reduce<Fq2>(c->sort_for_b(), c->work2, 0, 1, &S->B2, rs, tm);
   // what only needs the B2 sum continues on the `red` stream (never on the main stream: it is a
   // single-lane chain)
   G16_HIP(hipEventRecord(c->ev_b2, rs));
@@ -565,6 +598,7 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     G16_HIP(hipEventCreateWithFlags(&c->ev_b2, hipEventDisableTiming));
     for (auto& e : c->ev_acc) G16_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_fixed, hipEventDisableTiming));
+    G16_HIP(hipEventCreateWithFlags(&c->ev_view, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_send, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_part, hipEventDisableTiming));
     G16_HIP(hipEventCreateWithFlags(&c->ev_user, hipEventDisableTiming));
@@ -670,6 +704,36 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     // A and B1 are gathered by the same (scalar, digit, bucket) entries: interleaved point by point,
     // one 128-byte line serves both (G16_NO_PAIR_AB=1: separate arrays, for A/B measurements)
     static const bool no_pair = [] { const char* e = getenv("G16_NO_PAIR_AB"); return e && atoi(e) != 0; }();
+    // Sparse B queries: count the points at infinity of b_g1_query[1..] (b_g2_query has the same pattern:
+    // both are b_i(tau) times a generator).  From 1/8 of the wires on, B1 and B2 run over a filtered view
+    // of the witness sort (ctx.h: sort_b) -- single-device proving ctxs of >= 2^15 wires; G16_SPARSE_B=0 / 1
+    // (diagnostic, tested) overrides the rule.  A and B1 are then separate arrays (different entry lists).
+    if (lender) {
+      c->sparse_b = lender->sparse_b && c->world == 1;
+      c->keep_b = lender->keep_b;
+      c->b_inf_points = lender->b_inf_points;
+    } else if (c->world == 1 && !c->dist_wm && lw) {
+      std::vector<uint32_t> bits((lw + 31) / 32, 0u);
+      uint32_t inf = 0;
+      const uint8_t* b1 = key->b_g1_query + 64;
+      for (uint32_t i = 0; i < lw; ++i) {
+        const uint8_t* pnt = b1 + (size_t)i * 64;
+        bool zero = true;
+        for (int k = 0; k < 64 && zero; ++k) zero = pnt[k] == 0;
+        if (zero) ++inf;
+        else bits[i >> 5] |= 1u << (i & 31);
+      }
+      c->b_inf_points = inf;
+      const char* e = getenv("G16_SPARSE_B");
+      c->sparse_b = e ? atoi(e) != 0 : (lw >= (1u << 15) && (uint64_t)inf * 8 >= lw);
+      if (c->sparse_b) {
+        c->keep_b_own.alloc(bits.size());
+        G16_HIP(hipMemcpyAsync(c->keep_b_own.p, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, s));
+        G16_HIP(hipStreamSynchronize(s));  // `bits` is read by the async upload
+        c->keep_b = c->keep_b_own.p;
+      }
+    }
+    if (c->sparse_b) c->sort_b.init_view(lw, c->cfg_w);
     if (lender) {
       borrow(c->ptsA, lender->ptsA);
       borrow(c->ptsB1, lender->ptsB1);
@@ -677,7 +741,7 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       borrow(c->ptsL, lender->ptsL);
       c->l_idx_min = lender->l_idx_min;
     } else {
-      if (no_pair) {
+      if (no_pair || c->sparse_b) {
         c->ptsA.init((const G1Affine*)key->a_query + 1 + c->w_lo, lw, c->cfg_w, s);
         c->ptsB1.init((const G1Affine*)key->b_g1_query + 1 + c->w_lo, lw, c->cfg_w, s);
       } else {
@@ -857,6 +921,7 @@ void g16_ctx_destroy(g16_ctx* c) {
   for (auto e : c->ev_acc)
     if (e) (void)hipEventDestroy(e);
   if (c->ev_fixed) (void)hipEventDestroy(c->ev_fixed);
+  if (c->ev_view) (void)hipEventDestroy(c->ev_view);
   if (c->ev_send) (void)hipEventDestroy(c->ev_send);
   if (c->ev_part) (void)hipEventDestroy(c->ev_part);
   if (c->ev_user) (void)hipEventDestroy(c->ev_user);
@@ -1206,7 +1271,16 @@ g16_status g16_ctx_info(const g16_ctx* c, uint32_t out[16]) {
   out[10] = c->w_hi - c->w_lo;
   out[11] = c->h_hi - c->h_lo;
   out[13] = c->world > 1 ? (c->shard_buckets ? G16_SHARD_BUCKETS : G16_SHARD_POINTS) : 0;
-  out[15] = c->tbl.active ? 1u : 0u;
+  out[15] = (c->tbl.active ? 1u : 0u) | (c->sparse_b ? 2u : 0u);
+  return G16_OK;
+}
+
+g16_status g16_multi_links(const g16_ctx* c, float* gbps, float* echo_us, int cap, uint64_t* probe_bytes) {
+  if (!c || cap < 0) return G16_ERR_INVALID;
+  size_t pb = 0;
+  const int g = multi_links(c, gbps, echo_us, cap, &pb);
+  if (g < 0) return fail(const_cast<g16_ctx*>(c), G16_ERR_INVALID, "g16_multi_links: not a multi-device ctx");
+  if (probe_bytes) *probe_bytes = pb;
   return G16_OK;
 }
 

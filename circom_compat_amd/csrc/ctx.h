@@ -27,7 +27,7 @@ struct g16_ctx {
   hipStream_t aux = nullptr;   // witness map + H-query sort, beside the witness-scalar MSMs
   hipStream_t red = nullptr;   // G2 bucket reduction, underneath the H MSM
   hipEvent_t ev_start = nullptr, ev_ab = nullptr, ev_side = nullptr, ev_w = nullptr, ev_h = nullptr,
-             ev_b2 = nullptr, ev_fixed = nullptr;
+             ev_b2 = nullptr, ev_fixed = nullptr, ev_view = nullptr;  // ev_view: the filtered B view is built
   hipEvent_t ev_acc[3] = {nullptr, nullptr, nullptr};
   // sharded provers: hand-off points of the exchanges (no host synchronisation in between)
   hipEvent_t ev_send = nullptr;  // aux stream: the send buffer of the last phase is complete
@@ -60,6 +60,15 @@ struct g16_ctx {
   uint32_t l_idx_min = 0;  // entries below this local index have no L point (public inputs)
   g16::MsmConfig cfg_w, cfg_h;
   g16::MsmSort sort_w, sort_h;
+  // Sparse B queries (real circom keys: wires that appear in no B row have the point at infinity in
+  // b_g1_query / b_g2_query): sort_b = the witness sort without those points (MsmSort::run_view); B1 and
+  // B2 accumulate and reduce over it.  keep_b: one bit per entry i (wire i + 1), set when the point is finite.
+  g16::MsmSort sort_b;
+  g16::DevBuf<uint32_t> keep_b_own;
+  const uint32_t* keep_b = nullptr;
+  bool sparse_b = false;
+  uint32_t b_inf_points = 0;  // points at infinity among b_g1_query[1..] (reported by g16_ctx_info)
+  const g16::MsmSort& sort_for_b() const { return sparse_b ? sort_b : sort_w; }
   g16::MsmPoints<g16::Fq> ptsA, ptsB1, ptsL, ptsH;
   g16::MsmPoints<g16::Fq2> ptsB2;
   g16::MsmWork<g16::Fq> work1, workH;  // witness-scalar G1 MSMs (A, B1, L) / H MSM
@@ -127,5 +136,7 @@ g16_status multi_prove(g16_ctx* parent, const uint64_t r[4], const uint64_t s[4]
 g16_status multi_witness_upload(g16_ctx* parent, const uint64_t* w);
 g16_ctx* multi_child(g16_ctx* parent, int index);  // nullptr when out of range / not a parent
 int multi_size(const g16_ctx* parent);
+// create-time link probe of a multi-device parent: [src * G + dst] tables; returns G, -1 if not a parent
+int multi_links(const g16_ctx* parent, float* gbps, float* echo_us, int cap, size_t* probe_bytes);
 
 }  // namespace g16

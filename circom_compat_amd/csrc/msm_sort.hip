@@ -308,9 +308,19 @@ __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const void* scalars
 }
 
 // level 2, pass A: per-bucket counts.  total = part_off[bins1] (device side).
+// keep (optional): one bit per point index; pairs of points whose bit is clear are left out of the view
+// (the B queries of real circom keys hold a point at infinity for every wire that appears in no B row)
+__device__ __forceinline__ bool pair_kept(const uint32_t* __restrict__ keep, uint32_t idx_mask, uint32_t entry) {
+  if (!keep) return true;
+  const uint32_t idx = entry & idx_mask;
+  return (keep[idx >> 5] >> (idx & 31u)) & 1u;
+}
+
+template <bool FILTER>
 __global__ void __launch_bounds__(P2_THREADS) k_bucket_count(const MsmPair* part,
                                                              const uint32_t* total_ptr, int sh,
-                                                             uint32_t* count) {
+                                                             uint32_t* count, const uint32_t* keep,
+                                                             uint32_t idx_mask) {
   __shared__ uint32_t h[P2_BINS];
   const int tid = threadIdx.x;
   const uint32_t total = *total_ptr;
@@ -323,23 +333,46 @@ __global__ void __launch_bounds__(P2_THREADS) k_bucket_count(const MsmPair* part
     if (range <= (uint32_t)P2_BINS) {
       for (uint32_t b = tid; b < range; b += P2_THREADS) h[b] = 0;
       __syncthreads();
-      for (uint32_t j0 = lo + tid; j0 < hi; j0 += 8 * P2_THREADS) {  // eight loads in flight
-        uint32_t y[8];
+      if (FILTER) {
+        // the view: whole pairs, eight in flight, then the bitmap lookups, then the LDS counts (the
+        // register pattern of k_bucket_scatter below)
+        constexpr uint32_t NONE = 0xffffffffu;
+        for (uint32_t j0 = lo + tid; j0 < hi; j0 += 8 * P2_THREADS) {
+          MsmPair pe[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const uint32_t j = j0 + (uint32_t)u * P2_THREADS;
-          y[u] = j < hi ? part[j].y : 0xffffffffu;
+          for (int u = 0; u < 8; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * P2_THREADS;
+            pe[u] = j < hi ? part[j] : MsmPair{0u, NONE};
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (pe[u].y != NONE && !pair_kept(keep, idx_mask, pe[u].x)) pe[u].y = NONE;
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (pe[u].y != NONE) atomicAdd(&h[pe[u].y - gmin], 1u);
         }
+      } else {
+        for (uint32_t j0 = lo + tid; j0 < hi; j0 += 8 * P2_THREADS) {  // eight loads in flight
+          uint32_t y[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (y[u] != 0xffffffffu) atomicAdd(&h[y[u] - gmin], 1u);
+          for (int u = 0; u < 8; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * P2_THREADS;
+            y[u] = j < hi ? part[j].y : 0xffffffffu;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (y[u] != 0xffffffffu) atomicAdd(&h[y[u] - gmin], 1u);
+        }
       }
       __syncthreads();
       for (uint32_t b = tid; b < range; b += P2_THREADS)
         if (h[b]) atomicAdd(&count[gmin + b], h[b]);
       __syncthreads();
     } else {  // sparse buckets (tiny inputs or huge windows): plain global atomics
-      for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) atomicAdd(&count[part[j].y], 1u);
+      for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) {
+        const MsmPair pe = part[j];
+        if (!FILTER || pair_kept(keep, idx_mask, pe.x)) atomicAdd(&count[pe.y], 1u);
+      }
     }
   }
 }
@@ -348,9 +381,11 @@ __global__ void __launch_bounds__(P2_THREADS) k_bucket_count(const MsmPair* part
 // thread, all loads in flight together), counted into the LDS histogram, and scattered from the
 // registers after the chunk's runs have been reserved.
 constexpr int P2S_PER = 32, P2S_CHUNK = P2_THREADS * P2S_PER, P2S_GROUP = 8;
+template <bool FILTER>
 __global__ void __launch_bounds__(P2_THREADS) k_bucket_scatter(const MsmPair* part,
                                                                const uint32_t* total_ptr, int sh,
-                                                               uint32_t* cursor, uint32_t* entries) {
+                                                               uint32_t* cursor, uint32_t* entries,
+                                                               const uint32_t* keep, uint32_t idx_mask) {
   __shared__ uint32_t h[P2_BINS];
   const int tid = threadIdx.x;
   const uint32_t total = *total_ptr;
@@ -368,6 +403,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_bucket_scatter(const MsmPair* pa
       for (int u = 0; u < P2S_PER; ++u) {
         const uint32_t j = lo + (uint32_t)u * P2_THREADS + tid;
         pe[u] = j < hi ? part[j] : MsmPair{0u, NONE};
+        if (FILTER && pe[u].y != NONE && !pair_kept(keep, idx_mask, pe[u].x)) pe[u].y = NONE;
       }
       __syncthreads();
 #pragma unroll
@@ -394,7 +430,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_bucket_scatter(const MsmPair* pa
     } else {  // sparse buckets (tiny inputs or huge windows): plain global atomics
       for (uint32_t j = lo + tid; j < hi; j += P2_THREADS) {
         const MsmPair pe = part[j];
-        entries[atomicAdd(&cursor[pe.y], 1u)] = pe.x;
+        if (!FILTER || pair_kept(keep, idx_mask, pe.x)) entries[atomicAdd(&cursor[pe.y], 1u)] = pe.x;
       }
     }
   }
@@ -598,17 +634,66 @@ void MsmSort::run(const void* scalars, uint32_t n, bool mont, hipStream_t s) {
                part.p, rng);
   // level 2: bucket sizes, offsets, final placement (over this rank's pairs only when sharded)
   const uint32_t* total = rng ? rng + 3 : part_off.p + G.bins1;
-  G16_LAUNCH(k_bucket_count, grid2, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, count.p);
+  G16_LAUNCH((k_bucket_count<false>), grid2, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, count.p,
+             (const uint32_t*)nullptr, 0u);
   scan_exclusive(count.p, nb, 0, offset.p, cursor.p, scan_tmp.p, s);
   uint32_t grid3 = ceil_div((uint64_t)n * cfg.W, P2S_CHUNK);
   if (grid3 > 2 * grid_cap) grid3 = 2 * grid_cap;
   if (grid3 < 1) grid3 = 1;
-  G16_LAUNCH(k_bucket_scatter, grid3, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, cursor.p,
-             entries.p);
+  G16_LAUNCH((k_bucket_scatter<false>), grid3, P2_THREADS, 0, s, (const MsmPair*)part.p, total, G.sh, cursor.p,
+             entries.p, (const uint32_t*)nullptr, 0u);
   G16_LAUNCH(k_find_large, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)offset.p, nb, cfg.lanes,
              multi_l.p, meta.p);
   G16_LAUNCH(k_find_large, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)offset.p, nb, cfg.lanes2,
              multi_l2.p, meta2.p);
+}
+
+// ---- a filtered view of another sort: level 2 again over `src`'s level-1 pairs, leaving out the
+// points whose bit in `keep` is clear.  Same bucket ids, same configuration, own offsets / entries /
+// hot-bucket lists: everything the accumulation and reduction kernels read from an MsmSort.
+void MsmSort::init_view(uint32_t capacity, const MsmConfig& c) {
+  cfg = c;
+  cap = capacity;
+  const uint32_t nb = cfg.nb();
+  const uint64_t M = (uint64_t)cap * cfg.W;
+  count.alloc((size_t)nb + 1);
+  offset.alloc((size_t)nb + 1);
+  cursor.alloc((size_t)nb + 1);
+  entries.alloc(M ? M : 1);
+  multi_l.alloc((size_t)(M / ((uint64_t)MSM_MIN_SEG * MSM_SMALL_MULTI)) + 2);
+  meta.alloc(4);
+  multi_l2.alloc((size_t)(M / ((uint64_t)MSM_MIN_SEG * MSM_SMALL_MULTI)) + 2);
+  meta2.alloc(4);
+  scan_tmp.alloc(ceil_div((uint64_t)nb + 1, SCAN_TILE) + 1);
+}
+
+void MsmSort::run_view(const MsmSort& src, const uint32_t* keep_bits, hipStream_t s) {
+  if (src.world > 1) throw std::runtime_error("MsmSort::run_view: the source sort is sharded");
+  len = src.len;
+  const uint32_t nb = cfg.nb(), n = src.len;
+  const int sh = msm_part_shift(nb);
+  const uint32_t bins1 = ((nb - 1) >> sh) + 1;
+  const uint32_t idx_mask = (1u << cfg.idx_bits) - 1u;
+  G16_HIP(hipMemsetAsync(count.p, 0, ((size_t)nb + 1) * 4, s));
+  G16_HIP(hipMemsetAsync(meta.p, 0, 16, s));
+  G16_HIP(hipMemsetAsync(meta2.p, 0, 16, s));
+  const uint32_t grid_cap = sort_grid_cap();
+  uint32_t grid2 = ceil_div((uint64_t)n * cfg.W, P2_CHUNK);
+  if (grid2 > grid_cap) grid2 = grid_cap;
+  if (grid2 < 1) grid2 = 1;
+  const uint32_t* total = src.part_off.p + bins1;
+  G16_LAUNCH((k_bucket_count<true>), grid2, P2_THREADS, 0, s, (const MsmPair*)src.part.p, total, sh, count.p,
+             keep_bits, idx_mask);
+  scan_exclusive(count.p, nb, 0, offset.p, cursor.p, scan_tmp.p, s);
+  uint32_t grid3 = ceil_div((uint64_t)n * cfg.W, P2S_CHUNK);
+  if (grid3 > 2 * grid_cap) grid3 = 2 * grid_cap;
+  if (grid3 < 1) grid3 = 1;
+  G16_LAUNCH((k_bucket_scatter<true>), grid3, P2_THREADS, 0, s, (const MsmPair*)src.part.p, total, sh, cursor.p,
+             entries.p, keep_bits, idx_mask);
+  G16_LAUNCH(k_find_large, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)offset.p, nb, cfg.lanes, multi_l.p,
+             meta.p);
+  G16_LAUNCH(k_find_large, ceil_div(nb, 256), 256, 0, s, (const uint32_t*)offset.p, nb, cfg.lanes2, multi_l2.p,
+             meta2.p);
 }
 
 }  // namespace g16

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <vector>
 
@@ -183,6 +184,10 @@ struct Multi {
   };
   std::vector<std::unique_ptr<Dev>> dv;  // DevBuf is not movable
   bool witness_resident = false;  // g16_witness_upload: every child's w_dev holds the current witness
+  // create-time probe of every ordered (source, destination) pair (multi_link_probe): GB/s of one large
+  // peer copy, microseconds of a 4 KiB there-and-back; [src * G + dst]
+  std::vector<float> link_gbps, link_echo_us;
+  size_t link_probe_bytes = 0;
   StageRunner pool;
 };
 
@@ -301,6 +306,55 @@ __global__ void __launch_bounds__(256) k_selftest_check(const int32_t* recv, int
   if (mode == 0) send2[(size_t)src * stride + i] = (int32_t)(got ^ ST_ECHO);
 }
 
+// What the links deliver, measured with the copies a proof makes (hipMemcpyPeerAsync from the source's
+// exchange buffer into the destination's, on the source's copy stream for that destination): one copy
+// of up to 64 MiB timed by events on that stream, and a 4 KiB copy there and back timed on the host.
+// One pair at a time, at create: the figures are the uncontended per-link rates that
+// scripts/dist_projection.py assumes (48 GB/s per xGMI link) -- on the first multi-GPU box they are a
+// measurement instead (g16_multi_links; scripts/hardware_day.sh prints the table).
+void multi_link_probe(Multi& M) {
+  const int G = M.G;
+  M.link_gbps.assign((size_t)G * G, 0.f);
+  M.link_echo_us.assign((size_t)G * G, 0.f);
+  if (!M.dist) return;  // no exchange buffers: the replicated witness map moves 1 KiB records only
+  const size_t bytes = std::min<size_t>(M.dv[0]->send[0].bytes(), (size_t)64 << 20);
+  M.link_probe_bytes = bytes;
+  if (bytes < 4096) return;
+  for (int a = 0; a < G; ++a) {
+    g16_ctx* ca = M.ch[a];
+    G16_HIP(hipSetDevice(ca->device));
+    hipEvent_t e0, e1;
+    G16_HIP(hipEventCreate(&e0));
+    G16_HIP(hipEventCreate(&e1));
+    for (int b = 0; b < G; ++b) {
+      g16_ctx* cb = M.ch[b];
+      hipStream_t cs = M.dv[a]->cs[b];
+      // warm the path, then time one copy
+      G16_HIP(hipMemcpyPeerAsync(M.dv[b]->recv[0].p, cb->device, M.dv[a]->send[0].p, ca->device, 4096, cs));
+      G16_HIP(hipStreamSynchronize(cs));
+      G16_HIP(hipEventRecord(e0, cs));
+      G16_HIP(hipMemcpyPeerAsync(M.dv[b]->recv[0].p, cb->device, M.dv[a]->send[0].p, ca->device, bytes, cs));
+      G16_HIP(hipEventRecord(e1, cs));
+      G16_HIP(hipStreamSynchronize(cs));
+      float ms = 0.f;
+      G16_HIP(hipEventElapsedTime(&ms, e0, e1));
+      M.link_gbps[(size_t)a * G + b] = ms > 0.f ? (float)((double)bytes / (ms * 1e-3) / 1e9) : 0.f;
+      const auto t0 = std::chrono::steady_clock::now();
+      const int reps = 8;
+      for (int r = 0; r < reps; ++r) {
+        G16_HIP(hipMemcpyPeerAsync(M.dv[b]->recv[0].p, cb->device, M.dv[a]->send[0].p, ca->device, 4096, cs));
+        G16_HIP(hipStreamSynchronize(cs));
+        G16_HIP(hipMemcpyPeerAsync(M.dv[a]->recv[1].p, ca->device, M.dv[b]->recv[0].p, cb->device, 4096, cs));
+        G16_HIP(hipStreamSynchronize(cs));
+      }
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      M.link_echo_us[(size_t)a * G + b] = (float)(us / reps);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+}
+
 void multi_selftest(Multi& M) {
   const int G = M.G;
   const uint32_t T = M.dist ? (uint32_t)std::min<size_t>(M.chunk_ints, ST_WORDS) : 0u;
@@ -409,6 +463,18 @@ g16_ctx* multi_child(g16_ctx* parent, int index) {
   if (!parent || !parent->multi || index < 0 || index >= parent->multi->G) return nullptr;
   return parent->multi->ch[index];
 }
+int multi_links(const g16_ctx* parent, float* gbps, float* echo_us, int cap, size_t* probe_bytes) {
+  if (!parent || !parent->multi) return -1;
+  const Multi& M = *parent->multi;
+  const int n = M.G * M.G;
+  for (int i = 0; i < n && i < cap; ++i) {
+    if (gbps) gbps[i] = i < (int)M.link_gbps.size() ? M.link_gbps[i] : 0.f;
+    if (echo_us) echo_us[i] = i < (int)M.link_echo_us.size() ? M.link_echo_us[i] : 0.f;
+  }
+  if (probe_bytes) *probe_bytes = M.link_probe_bytes;
+  return M.G;
+}
+
 int multi_size(const g16_ctx* parent) { return (parent && parent->multi) ? parent->multi->G : 0; }
 
 void multi_destroy(Multi* M) {
@@ -526,6 +592,7 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
       if (peer_state != 1)
         fprintf(stderr, "libg16_amd: %s -- the exchanges of every proof will be staged by the runtime\n", why.c_str());
       multi_selftest(*M);
+      multi_link_probe(*M);
     } catch (const std::exception& e) {
       code = G16_ERR_HIP;
       M->pool.first_error = e.what();

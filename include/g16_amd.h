@@ -255,8 +255,19 @@ const char* g16_stage_name(int stage);
  * out[8] = domain_size, out[9] = log2(domain_size), out[10] / out[11] = points of the witness / H
  * shard (rank 0's for a multi-device ctx), out[12] = devices, out[13] = how a world > 1 ctx shards
  * (G16_SHARD_POINTS / G16_SHARD_BUCKETS; 0 for world = 1), out[14] = multi-device ctx: 1 when every
- * pair of its devices has direct peer access, 2 when some exchanges are staged by the runtime      */
+ * pair of its devices has direct peer access, 2 when some exchanges are staged by the runtime,
+ * out[15] = bit 0: g16_prove goes through the fixed-base tables (g16_options.fixed_tables); bit 1: the
+ * B1 / B2 MSMs run over a filtered view of the witness sort (>= 1/8 of b_g1_query is the point at
+ * infinity: wires that appear in no B row of a real circom circuit)                                 */
 g16_status g16_ctx_info(const g16_ctx* ctx, uint32_t out[16]);
+/* Multi-device ctx (g16_ctx_create_multi with a distributed witness map): what every ordered (source,
+ * destination) pair of its ranks delivered at create time, measured with the copies a proof makes --
+ * gbps[src * n + dst] = GB/s of one peer copy of *probe_bytes (<= 64 MiB) from src's exchange buffer
+ * into dst's; echo_us[src * n + dst] = microseconds of a 4 KiB copy there and back (host-timed, launch
+ * latency included).  n = g16_ctx_info out[12]; at most `cap` entries of each table are written.  The
+ * reference has nothing to compare (single process, CPU); this is the per-link figure the scaling
+ * projection assumes, turned into a measurement on the first multi-GPU box.      */
+g16_status g16_multi_links(const g16_ctx* ctx, float* gbps, float* echo_us, int cap, uint64_t* probe_bytes);
 /* device pointer of the ctx's witness staging buffer (n_vars x 32 bytes) for g16_prove_dev        */
 void* g16_witness_buffer(g16_ctx* ctx);
 /* Makes the witness resident: copies it into the ctx's device staging buffer -- into EVERY device's

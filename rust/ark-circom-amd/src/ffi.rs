@@ -183,6 +183,7 @@ extern "C" {
     pub fn g16_stage_times(ctx: *mut g16_ctx, ms: *mut c_float, launches: *mut u32) -> g16_status;
     pub fn g16_stage_name(stage: c_int) -> *const c_char;
     pub fn g16_ctx_info(ctx: *const g16_ctx, out: *mut u32) -> g16_status;
+    pub fn g16_multi_links(ctx: *const g16_ctx, gbps: *mut f32, echo_us: *mut f32, cap: c_int, probe_bytes: *mut u64) -> g16_status;
     pub fn g16_witness_buffer(ctx: *mut g16_ctx) -> *mut c_void;
     pub fn g16_witness_upload(ctx: *mut g16_ctx, w: *const u64, n_vars: usize) -> g16_status;
     pub fn g16_witness_host_buffer(ctx: *mut g16_ctx) -> *mut c_void;

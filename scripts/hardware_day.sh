@@ -56,6 +56,16 @@ for n in (2, 4, 8):
         got = pr.prove(rs[0], rs[1], w).raw
         print(f"N={n} {shard}: self-test passed, peer_access={info['peer_access']} (1 = direct for every pair, 2 = some staged), "
               f"bytes == single-GPU proof: {got == want}")
+        if shard == "points":
+            # the create-time link probe (g16_multi_links): GB/s of one large peer copy per ordered pair, and a
+            # 4 KiB there-and-back -- the measurement behind the 48 GB/s-per-link figure of scripts/dist_projection.py
+            lk = pr.links()
+            off = [lk["gbps"][a][b] for a in range(n) for b in range(n) if a != b]
+            echo = [lk["echo_us"][a][b] for a in range(n) for b in range(n) if a != b]
+            print(f"N={n} links ({lk['probe_bytes'] >> 20} MiB per copy): GB/s min {min(off):.1f} / max {max(off):.1f}; "
+                  f"4 KiB there-and-back us min {min(echo):.1f} / max {max(echo):.1f}")
+            for a in range(n):
+                print("   from rank %d: " % a + " ".join("%7.1f" % x for x in lk["gbps"][a]))
         pr.close()
 PY
 echo "== 2. bench.py in-library, N = 1, 2, 4, 8"

@@ -303,6 +303,18 @@ def test_full_prove_headline_sizes_bytes_pairing_and_qap_identities(gpulib, k):
     W = -sum(xs[j + 1] * L[j] for j in range(m)) % R
     assert lhs == (U * V - W) * di % R, "QAP identity fails on the GPU witness map"
     assert pr.msm_g1(3, cc.fr_from_ints(h)) == o.g1_to_bytes(o.G1.mul(o.G1_GEN, lhs))
+    # ---- the filtered B view (ctx.h sort_b; what a key with >= 1/8 points at infinity in its B queries
+    # selects) in this size's schedule branch (2^20: reductions on the `red` stream, 2^22: everything in
+    # order): forced here on a key without such points, so the view holds every pair -- same bytes
+    if k <= 22:
+        os.environ["G16_SPARSE_B"] = "1"
+        try:
+            sp = cc.Prover(pk, mats)
+        finally:
+            del os.environ["G16_SPARSE_B"]
+        assert sp.info()["sparse_b"] == 1 and pr.info()["sparse_b"] == 0
+        assert sp.prove(rs[0], rs[1], w).raw == want, "filtered-B-view proof differs at 2^%d" % k
+        sp.close()
     # ---- BASELINE configs[3] as far as one GPU allows: the SAME circuit sharded over 8 ranks
     # (g16_ctx_create_multi, every rank on this GPU, MSMs cut by bucket range, distributed witness
     # map): bytes == the CPU proof above; a second proof with other (r, s) verifies
@@ -694,8 +706,20 @@ def test_real_poseidon_chain_2p20_through_zkey_one_gpu_and_8_ranks(gpulib, tmp_p
     rs = cc.fr_from_ints([rng.randrange(o.R_MOD), rng.randrange(o.R_MOD)])
     w = cc.fr_from_ints(w_ints)
     want = cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
-    proof = cc.Prover(pk, mats).prove(rs[0], rs[1], w)
+    one = cc.Prover(pk, mats)
+    # every x4 wire of an S-box appears in A only: a third of b_g1_query / b_g2_query is the point at
+    # infinity, and the B1 / B2 MSMs run over the filtered view of the witness sort
+    assert one.info()["sparse_b"] == 1
+    proof = one.prove(rs[0], rs[1], w)
+    one.close()
     assert proof.raw == want
+    os.environ["G16_SPARSE_B"] = "0"
+    try:
+        full = cc.Prover(pk, mats)
+    finally:
+        del os.environ["G16_SPARSE_B"]
+    assert full.info()["sparse_b"] == 0 and full.prove(rs[0], rs[1], w).raw == want
+    full.close()
     assert o.verify_proof(_vk_dict(pk), [chain[-1]], H.proof_from_bytes(proof.raw))
     assert not o.verify_proof(_vk_dict(pk), [(chain[-1] + 1) % o.R_MOD], H.proof_from_bytes(proof.raw))
     for shard in ("points", "buckets"):

@@ -324,8 +324,8 @@ def test_memory_plan_falls_back_to_fewer_planes_instead_of_refusing(emu, monkeyp
     want = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2, len(cons), w))
     WB = 4                       # W = 64 windows -> 32 planes at most, 40 KB per plane of the witness queries
 
-    def create(extra):           # the plan keeps 2 GiB + 2 % of the free memory out of its budget
-        monkeypatch.setenv("G16_EMU_FREE_BYTES", str(int(((2 << 30) + extra) / 0.98)))
+    def create(extra):           # the plan keeps min(2 GiB + 2 %, a quarter) of the free memory out of its budget:
+        monkeypatch.setenv("G16_EMU_FREE_BYTES", str(int(extra / 0.75) + 1))   # a budget of `extra` bytes
         try:
             return cc.Prover(pk, mats, lib=emu, window_bits=WB)
         except Exception as e:
@@ -1079,3 +1079,82 @@ def test_more_wires_than_the_domain(lib, n_rows):
         pr = cc.Prover(pk, mats, lib=lib, devices=[0] * 4, shard=shard)
         assert pr.prove(r, s, w).raw == want
         pr.close()
+
+
+@pytest.mark.parametrize("wb", [0, 6])
+def test_sparse_b_queries_use_a_filtered_view_of_the_witness_sort(lib, monkeypatch, wb):
+    """Real circom keys hold the point at infinity in b_g1_query / b_g2_query for every wire that appears
+    in no B row.  With G16_SPARSE_B=1 (the automatic rule needs >= 2^15 wires: GPU suite) B1 and B2
+    accumulate and reduce over MsmSort::run_view -- level 2 of the witness sort re-run without those
+    points -- and A / B1 are separate arrays.  A circuit whose B rows touch a quarter of the wires (and a
+    0/1-heavy witness: hot buckets in both views): proof bytes == the oracle's == the unfiltered path's,
+    with the default window and with c = 6 (several buckets per sort partition); a sibling inherits the view."""
+    import circom_compat_amd as cc
+    rng = random.Random(4242 + wb)
+    P = o.R_MOD
+    w = [1, 0]
+    cons = []
+    for i in range(60):
+        a, b = rng.randrange(P), rng.choice([0, 1, 1, rng.randrange(P)])
+        base = len(w)
+        w.extend([a, rng.randrange(2), rng.randrange(P), 0])
+        if i % 4 == 0:       # one row in four has its own B wire; the others multiply by wire `base + 1` of row 0 or by one
+            w[base + 1] = b
+            cons.append(([(base, 1), (base + 2, 3)], [(base + 1, 1)], [(base + 3, 1)]))
+            w[base + 3] = (a + 3 * w[base + 2]) * b % P
+        else:
+            cons.append(([(base, 1), (base + 1, 2)], [(0, 1)], [(base + 3, 1)]))
+            w[base + 3] = (a + 2 * w[base + 1]) % P
+    cons.append(([(len(w) - 1, 1)], [(0, 1)], [(1, 1)]))
+    w[1] = w[-1]
+    n_vars = len(w)
+    opk = o.trapdoor_setup(cons, n_vars, 1, *[rng.randrange(1, P) for _ in range(5)])
+    n_inf = sum(1 for p in opk["b_g1_query"][1:] if p is None)
+    assert n_inf * 8 >= n_vars and all((p is None) == (q is None) for p, q in zip(opk["b_g1_query"], opk["b_g2_query"]))
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, lib)
+    pk = H.pk_from_oracle(opk)
+    plain = cc.Prover(pk, mats, lib=lib, window_bits=wb)
+    assert plain.info()["sparse_b"] == 0
+    monkeypatch.setenv("G16_SPARSE_B", "1")
+    view = cc.Prover(pk, mats, lib=lib, window_bits=wb)
+    assert view.info()["sparse_b"] == 1
+    sib = cc.Prover(pk, mats, lib=lib, sibling_of=view, window_bits=wb)
+    assert sib.info()["sparse_b"] == 1
+    monkeypatch.delenv("G16_SPARSE_B")
+    for _ in range(2):
+        r, s = rng.randrange(P), rng.randrange(P)
+        want = o.proof_to_bytes(o.create_proof_with_reduction_and_matrices(opk, r, s, dict(a=a_rows, b=b_rows), 2,
+                                                                           len(cons), w))
+        assert view.prove(r, s, w).raw == want
+        assert plain.prove(r, s, w).raw == want
+        assert sib.prove(r, s, w).raw == want
+
+
+def test_multi_device_ctx_reports_its_link_probe(lib):
+    """g16_multi_links: the create-time probe of every ordered (source, destination) pair of a multi-device
+    ctx with a distributed witness map -- one table entry per pair (the local pair included), the probed
+    copy size, finite non-negative figures (on the GPU: positive; the emulator has no clock); a ctx
+    without exchange buffers (3 ranks: replicated witness map) reports zeros; a single-device ctx is an
+    error."""
+    import circom_compat_amd as cc
+    cons, w, n_vars, n_pub = H.squaring_chain(8)      # exchange buffers of 13.5 KiB: the probe needs >= 4 KiB
+    rng = random.Random(57)
+    opk = o.trapdoor_setup(cons, n_vars, n_pub, *[rng.randrange(1, o.R_MOD) for _ in range(5)])
+    a_rows, b_rows = o.matrices_from_r1cs(cons)
+    mats = H.matrices_from_rows(a_rows, b_rows, 2, n_vars, lib)
+    pk = H.pk_from_oracle(opk)
+    pr = cc.Prover(pk, mats, lib=lib, devices=[0, 0])
+    lk = pr.links()
+    assert len(lk["gbps"]) == 2 and all(len(r) == 2 for r in lk["gbps"]) and lk["probe_bytes"] >= 4096
+    flat = [x for r in lk["gbps"] for x in r] + [x for r in lk["echo_us"] for x in r]
+    assert all(x >= 0.0 and x == x and x < 1e9 for x in flat)
+    if not lib.path.endswith("libg16_emu.so"):
+        assert all(x > 0.0 for x in flat)
+    pr.close()
+    p3 = cc.Prover(pk, mats, lib=lib, devices=[0, 0, 0])
+    assert all(x == 0.0 for r in p3.links()["gbps"] for x in r)
+    p3.close()
+    one = cc.Prover(pk, mats, lib=lib)
+    with pytest.raises(cc.G16Error):
+        one.links()
