@@ -135,16 +135,13 @@ void collect_times(g16_ctx* c) {
   if (c->timer.enabled) c->timer.collect(c->st_ms, c->st_cnt);
 }
 
-void wait_for_b_view(g16_ctx* c, hipStream_t s);
-
 // A and B1 accumulations into work1 slots 0 and 1: one launch over the interleaved pair, or two
 void accumulate_ab(g16_ctx* c, hipStream_t s, StageTimer* tm, bool fixup = true) {
   if (c->ptsA.stride == 2) {
     msm_accumulate_pair<Fq>(c->sort_w, c->ptsA, c->ptsB1, c->work1, 0, s, tm, fixup);
   } else {
     msm_accumulate<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, s, tm, fixup);
-    wait_for_b_view(c, s);
-    msm_accumulate<Fq>(c->sort_for_b(), c->ptsB1, 0, c->work1, 1, s, tm, fixup);
+    msm_accumulate<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, s, tm, fixup);
   }
 }
 // the deferred exact additions of accumulate_ab(fixup = false), on the stream that reduces A and B1
@@ -154,22 +151,8 @@ void fixup_ab(g16_ctx* c, hipStream_t q) {
     msm_fixup_pair<Fq>(c->sort_w, c->ptsA, c->ptsB1, c->work1, 0, q, tm);
   } else {
     msm_fixup<Fq>(c->sort_w, c->ptsA, 0, c->work1, 0, q, tm);
-    msm_fixup<Fq>(c->sort_for_b(), c->ptsB1, 0, c->work1, 1, q, tm);
+    msm_fixup<Fq>(c->sort_w, c->ptsB1, 0, c->work1, 1, q, tm);
   }
-}
-
-// bucket reductions of work1 slots 0 .. n - 1 (A, B1[, L]) into ProofSums (A, B1, L are adjacent there): ONE
-// batched launch over the witness sort -- unless B1 was accumulated over the filtered view (sparse B),
-// whose bucket offsets are its own
-void reduce_abl(g16_ctx* c, int n, hipStream_t q, StageTimer* tm, bool hidden) {
-  ProofSums* S = c->sums_dev.p;
-  if (!c->sparse_b) {
-    msm_reduce<Fq>(c->sort_w, c->work1, 0, n, &S->A, q, tm, hidden);
-    return;
-  }
-  msm_reduce<Fq>(c->sort_w, c->work1, 0, 1, &S->A, q, tm, hidden);
-  msm_reduce<Fq>(c->sort_b, c->work1, 1, 1, &S->B1, q, tm, hidden);
-  if (n == 3) msm_reduce<Fq>(c->sort_w, c->work1, 2, 1, &S->L, q, tm, hidden);
 }
 
 // main stream: witness-scalar sort, then the A, B1, L, B2 MSMs (ALU bound).  `after_ab` is called
@@ -182,9 +165,8 @@ void enqueue_witness_sort(g16_ctx* c, const Fr* w_dev) {
   c->sort_w.run(w_dev + 1 + c->w_lo, c->w_hi - c->w_lo, /*mont=*/true, s);
   if (tm) tm->end(id, s);
   if (c->sparse_b) {
-    // the filtered view is built beside the A accumulation (which reads the full sort): on the `red`
-    // stream, B1 waits for ev_view (wait_for_b_view).  On the main stream it sat in front of everything:
-    // +1.1 ms at 2^20 (profiles/r05_sparse_b_ab.txt)
+    // the filtered view is built beside the A | B1 accumulation (which reads the full sort): on the `red`
+    // stream; the B2 launch waits for ev_view (wait_for_b_view)
     hipStream_t v = c->overlap ? c->red : s;
     G16_HIP(hipEventRecord(c->ev_view, s));
     G16_HIP(hipStreamWaitEvent(v, c->ev_view, 0));
@@ -238,8 +220,9 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     G16_HIP(hipEventRecord(c->ev_acc[0], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[0], 0));
     fixup_ab(c, q);
-    reduce_abl(c, 2, q, tm, /*hidden=*/true);
+    msm_reduce<Fq>(c->sort_w, c->work1, 0, 2, &S->A, q, tm, /*hidden=*/true);
     after_ab(q);
+    wait_for_b_view(c, s);
     msm_accumulate<Fq2>(c->sort_for_b(), c->ptsB2, 0, c->work2, 0, s, tm);
     G16_HIP(hipEventRecord(c->ev_acc[1], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[1], 0));
@@ -262,14 +245,14 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     // share of a sharded 2^22 proof.  ProofSums keeps A, B1, L adjacent.
     accumulate_ab(c, s, tm);
     msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm);
-    reduce_abl(c, 3, s, tm, false);
+    msm_reduce<Fq>(c->sort_w, c->work1, 0, 3, &S->A, s, tm);
     after_ab(s);
   } else {
     // large bucket sets: the reduction is throughput bound, and reducing A and B1 at once lets
     // the variable-base part of the finalisation start ~10 ms earlier (measured at 2^22: 41.3 vs
     // 43.0 ms per proof)
     accumulate_ab(c, s, tm);
-    reduce_abl(c, 2, s, tm, false);  // ProofSums keeps A, B1 adjacent
+    msm_reduce<Fq>(c->sort_w, c->work1, 0, 2, &S->A, s, tm);  // ProofSums keeps A, B1 adjacent
     after_ab(s);
     // (round 4, VERDICT r3 item 5: taking the L reduction off the main stream -- beside the H
     // accumulation, or beside the H reduction -- was built and measured: 37.67 / 37.50 ms shipped vs
@@ -281,6 +264,7 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
   // slots from it.  Measured on one box, batched reduction / own stream for the B2 reduction:
   //   2^14: 4.60 ms neither, 3.84 batched, 3.64 both;  2^18: 6.74 / 5.61 / 5.23;
   //   2^20: 13.56 / 13.05 / 13.21;  2^22: 40.1 / 41.9 / -.   ev_side = "everything forked is done".
+  wait_for_b_view(c, s);
   msm_accumulate<Fq2>(c->sort_for_b(), c->ptsB2, 0, c->work2, 0, s, tm);
   // sharded ranks: the main stream is the critical path (the witness-map phases and exchanges hide
   // under it), so the B2 reduction leaves it whenever the bucket set is small
@@ -705,9 +689,11 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     // one 128-byte line serves both (G16_NO_PAIR_AB=1: separate arrays, for A/B measurements)
     static const bool no_pair = [] { const char* e = getenv("G16_NO_PAIR_AB"); return e && atoi(e) != 0; }();
     // Sparse B queries: count the points at infinity of b_g1_query[1..] (b_g2_query has the same pattern:
-    // both are b_i(tau) times a generator).  From 1/8 of the wires on, B1 and B2 run over a filtered view
-    // of the witness sort (ctx.h: sort_b) -- single-device proving ctxs of >= 2^15 wires; G16_SPARSE_B=0 / 1
-    // (diagnostic, tested) overrides the rule.  A and B1 are then separate arrays (different entry lists).
+    // both are b_i(tau) times a generator).  From 1/8 of the wires on, the B2 MSM -- the G2 one, a third of
+    // a proof -- runs over a filtered view of the witness sort (ctx.h: sort_b): single-device proving ctxs
+    // of >= 2^15 wires; G16_SPARSE_B=0 / 1 (diagnostic, tested) overrides the rule.  B1 stays in the A | B1
+    // pair launch over the full sort (un-pairing it and reducing it on its own cost more launches than its
+    // third of additions is worth: profiles/r05_sparse_b_ab.txt).
     if (lender) {
       c->sparse_b = lender->sparse_b && c->world == 1;
       c->keep_b = lender->keep_b;
@@ -741,7 +727,7 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       borrow(c->ptsL, lender->ptsL);
       c->l_idx_min = lender->l_idx_min;
     } else {
-      if (no_pair || c->sparse_b) {
+      if (no_pair) {
         c->ptsA.init((const G1Affine*)key->a_query + 1 + c->w_lo, lw, c->cfg_w, s);
         c->ptsB1.init((const G1Affine*)key->b_g1_query + 1 + c->w_lo, lw, c->cfg_w, s);
       } else {

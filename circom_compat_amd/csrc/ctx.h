@@ -61,8 +61,8 @@ struct g16_ctx {
   g16::MsmConfig cfg_w, cfg_h;
   g16::MsmSort sort_w, sort_h;
   // Sparse B queries (real circom keys: wires that appear in no B row have the point at infinity in
-  // b_g1_query / b_g2_query): sort_b = the witness sort without those points (MsmSort::run_view); B1 and
-  // B2 accumulate and reduce over it.  keep_b: one bit per entry i (wire i + 1), set when the point is finite.
+  // b_g1_query / b_g2_query): sort_b = the witness sort without those points (MsmSort::run_view); the B2
+  // (G2) MSM accumulates and reduces over it.  keep_b: one bit per entry i (wire i + 1), set when the point is finite.
   g16::MsmSort sort_b;
   g16::DevBuf<uint32_t> keep_b_own;
   const uint32_t* keep_b = nullptr;

@@ -149,9 +149,9 @@ struct MsmSort {
   // scalars: `n` field elements (Montgomery Fr when mont, else canonical U256) in device memory
   void run(const void* scalars, uint32_t n, bool mont, hipStream_t stream);
   // A filtered VIEW of another (unsharded) sort over the same scalars: level 2 re-run over src's level-1
-  // pairs without the points whose bit in keep_bits is clear (msm_sort.hip).  The B1 / B2 queries of a
-  // real circom key hold the point at infinity for every wire that appears in no B row: a third of the
-  // wires of a Poseidon chain; the shared witness sort would spend a full mixed addition on each.
+  // pairs without the points whose bit in keep_bits is clear (msm_sort.hip).  The B queries of a real
+  // circom key hold the point at infinity for every wire that appears in no B row: a third of the wires
+  // of a Poseidon chain; the shared witness sort would spend a full G2 mixed addition on each.
   void init_view(uint32_t capacity, const MsmConfig& cfg);
   void run_view(const MsmSort& src, const uint32_t* keep_bits, hipStream_t stream);
   static size_t view_bytes_for(uint32_t capacity, const MsmConfig& cfg) {

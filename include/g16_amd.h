@@ -257,8 +257,8 @@ const char* g16_stage_name(int stage);
  * (G16_SHARD_POINTS / G16_SHARD_BUCKETS; 0 for world = 1), out[14] = multi-device ctx: 1 when every
  * pair of its devices has direct peer access, 2 when some exchanges are staged by the runtime,
  * out[15] = bit 0: g16_prove goes through the fixed-base tables (g16_options.fixed_tables); bit 1: the
- * B1 / B2 MSMs run over a filtered view of the witness sort (>= 1/8 of b_g1_query is the point at
- * infinity: wires that appear in no B row of a real circom circuit)                                 */
+ * B2 (G2) MSM runs over a filtered view of the witness sort (>= 1/8 of b_g1_query / b_g2_query is the
+ * point at infinity: wires that appear in no B row of a real circom circuit)                        */
 g16_status g16_ctx_info(const g16_ctx* ctx, uint32_t out[16]);
 /* Multi-device ctx (g16_ctx_create_multi with a distributed witness map): what every ordered (source,
  * destination) pair of its ranks delivered at create time, measured with the copies a proof makes --

@@ -708,7 +708,7 @@ def test_real_poseidon_chain_2p20_through_zkey_one_gpu_and_8_ranks(gpulib, tmp_p
     want = cpu_ref.prove(pk, mats, rs[0:1].copy(), rs[1:2].copy(), w)
     one = cc.Prover(pk, mats)
     # every x4 wire of an S-box appears in A only: a third of b_g1_query / b_g2_query is the point at
-    # infinity, and the B1 / B2 MSMs run over the filtered view of the witness sort
+    # infinity, and the B2 (G2) MSM runs over the filtered view of the witness sort
     assert one.info()["sparse_b"] == 1
     proof = one.prove(rs[0], rs[1], w)
     one.close()

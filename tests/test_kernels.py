@@ -1088,9 +1088,9 @@ def test_more_wires_than_the_domain(lib, n_rows):
 @pytest.mark.parametrize("wb", [0, 6])
 def test_sparse_b_queries_use_a_filtered_view_of_the_witness_sort(lib, monkeypatch, wb):
     """Real circom keys hold the point at infinity in b_g1_query / b_g2_query for every wire that appears
-    in no B row.  With G16_SPARSE_B=1 (the automatic rule needs >= 2^15 wires: GPU suite) B1 and B2
-    accumulate and reduce over MsmSort::run_view -- level 2 of the witness sort re-run without those
-    points -- and A / B1 are separate arrays.  A circuit whose B rows touch a quarter of the wires (and a
+    in no B row.  With G16_SPARSE_B=1 (the automatic rule needs >= 2^15 wires: GPU suite) the B2 (G2) MSM
+    accumulates and reduces over MsmSort::run_view -- level 2 of the witness sort re-run without those
+    points; B1 stays in the A | B1 pair launch.  A circuit whose B rows touch a quarter of the wires (and a
     0/1-heavy witness: hot buckets in both views): proof bytes == the oracle's == the unfiltered path's,
     with the default window and with c = 6 (several buckets per sort partition); a sibling inherits the view."""
     import circom_compat_amd as cc
