@@ -11,7 +11,7 @@
 #   3. bench.py at N = 2, 4, 8 with one process per GPU (G16_BENCH_MODE=ranks: RCCL all_to_all /
 #      all_gather over xGMI on the registered exchange stream), RCCL's rank count printed
 #   4. the scaling table T1 / (N x T_N) for both, next to the one-GPU projection of
-#      profiles/r04_proj_k24.json
+#      profiles/r05_proj_k24.json
 set -u
 K=${1:-24}; STEPS=${2:-10}
 cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -102,7 +102,7 @@ for mode in ("inlib", "ranks"):
         if t1 and t:
             print(f"{mode} N={n}: {t:.2f} ms, strong-scaling efficiency T1/(N T_N) = {t1 / (n * t):.3f}")
 try:
-    p = json.load(open("profiles/r04_proj_k24.json"))
+    p = json.load(open("profiles/r05_proj_k24.json"))
     for k, v in p["ranks"].items():
         print("one-GPU projection", k, round(v["efficiency_before_xgmi"], 3), "/ with all link time exposed", round(v["efficiency_if_all_link_time_exposed"], 3))
 except Exception as e:
