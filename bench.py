@@ -1001,6 +1001,8 @@ def main():
             dist.destroy_process_group()
         return
     if args.pmc_child:                # the profiled child of measure_pmc_traffic(): the proofs above are all it is for
+        if zkey_path and os.path.exists(zkey_path):
+            os.remove(zkey_path)
         return
     both_vals = None
     if both:
