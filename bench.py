@@ -704,6 +704,8 @@ def setup_prover(cc, torch, args, mode, rank, local_rank, n_gpus, world, one_gpu
         pk, mats = cc.read_zkey(zkey_path)
     kw = dict(window_bits=args.window_bits, planes=args.planes, shard=args.shard)
     if mode == "single":
+        kw["tables"] = {"auto": 0, "on": 1, "off": -1}[args.tables]
+    if mode == "single":
         prover = cc.Prover(pk, mats, device=local_rank, **kw)
     elif mode == "inlib":
         if os.environ.get("G16_BENCH_FAIL_INLIB"):   # exercises the fallback on a 1-GPU box
@@ -747,6 +749,8 @@ def main():
                     help="seconds of CPU work the baseline sample may take")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--planes", type=int, default=0)
+    ap.add_argument("--tables", choices=["auto", "on", "off"], default="auto",
+                    help="g16_options.fixed_tables: small keys through fixed-base tables (auto = the library's rule)")
     ap.add_argument("--shard", choices=["auto", "points", "buckets"], default="auto",
                     help="N > 1: MSMs cut by point range or by bucket range (auto = points)")
     ap.add_argument("--no-pmc", action="store_true",
@@ -1038,7 +1042,7 @@ def main():
     # (g16_ctx_create_sibling), one host thread each -- the front of one proof (digit sort, witness map)
     # runs under the bucket reductions / finalisation of the other
     pipelined = None
-    kw = dict(window_bits=args.window_bits, planes=args.planes)
+    kw = dict(window_bits=args.window_bits, planes=args.planes, tables={"auto": 0, "on": 1, "off": -1}[args.tables])
     if mode == "single" and args.mode == "prove" and not os.environ.get("G16_BENCH_NO_PIPELINE"):
         import threading
         try:
