@@ -886,4 +886,11 @@ def test_fixed_base_tables_reference_bench_circuit_and_limits(gpulib):
     pk2 = cc.trapdoor_setup(A2, B2, C2, nv2, 1, tox)
     big = cc.Prover(pk2, mats2, tables=0)
     assert big.info()["fixed_tables"] == 0
+    # ... and `tables=1` still forces the path there (51 GB of tables, within a third of 288 GB): same bytes
+    forced = cc.Prover(pk2, mats2, tables=1)
+    assert forced.info()["fixed_tables"] == 1
+    wv = cc.fr_from_ints(w2)
+    want2 = cpu_ref.prove(pk2, mats2, rs[0:1].copy(), rs[1:2].copy(), wv)
+    assert forced.prove(rs[0], rs[1], wv).raw == want2 and big.prove(rs[0], rs[1], wv).raw == want2
+    forced.close()
     big.close()
