@@ -601,17 +601,23 @@ class ClockSampler:
         # that IS HIP device `ordinal` is the one whose PCI address hipDeviceGetPCIBusId reports.
         hwmon = None
         try:
-            import ctypes
-            buf = ctypes.create_string_buffer(64)
-            hip = ctypes.CDLL("libamdhip64.so")
-            if hip.hipDeviceGetPCIBusId(buf, 64, int(ordinal)) == 0:
-                want = buf.value.decode().lower()
-                for c in glob.glob("/sys/class/drm/card[0-9]*"):
-                    if os.path.basename(os.path.realpath(os.path.join(c, "device"))).lower() == want:
-                        hw = sorted(glob.glob(os.path.join(c, "device", "hwmon", "hwmon*")))
-                        if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
-                            hwmon = hw[0]
-                        break
+            want = None
+            try:  # the runtime torch already holds: no second copy of libamdhip64 in the process
+                import torch
+                pr = torch.cuda.get_device_properties(int(ordinal))
+                want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            except Exception:  # noqa: BLE001 -- older torch: ask the HIP runtime the process has loaded
+                import ctypes
+                buf = ctypes.create_string_buffer(64)
+                hip = ctypes.CDLL("libamdhip64.so")
+                if hip.hipDeviceGetPCIBusId(buf, 64, int(ordinal)) == 0:
+                    want = buf.value.decode().lower()
+            for c in glob.glob("/sys/class/drm/card[0-9]*") if want else []:
+                if os.path.basename(os.path.realpath(os.path.join(c, "device"))).lower() == want:
+                    hw = sorted(glob.glob(os.path.join(c, "device", "hwmon", "hwmon*")))
+                    if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+                        hwmon = hw[0]
+                    break
         except Exception:  # noqa: BLE001 -- no sysfs view of the device: rocm-smi below
             hwmon = None
         self._freq = self._pow = None

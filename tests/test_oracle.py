@@ -267,7 +267,8 @@ def test_c_oracle_scalar_mul_matches_python_oracle():
 @pytest.mark.slow
 @pytest.mark.parametrize("logm", [12, 14, 16] + [pytest.param(k, marks=pytest.mark.skipif(
     not os.environ.get("G16_SLOW_PINS"), reason="opt-in (G16_SLOW_PINS=1): 1 / 5 min of pure-Python NTTs; "
-    "run once per round, log under profiles/")) for k in (18, 20)])
+    "run once per round, log under profiles/")) for k in (18, 20)] + [pytest.param(22, marks=pytest.mark.skipif(
+    os.environ.get("G16_SLOW_PINS") != "22", reason="opt-in (G16_SLOW_PINS=22): the headline size, ~20 min of pure-Python NTTs"))])
 def test_c_oracle_prove_matches_python_oracle_2p12_2p14(logm):
     """oracle/groth16_cpu.c's CircomReduction prove == oracle/bn254_ref.py at 2^12, 2^14 and 2^16
     constraints (default suite) and at 2^18 and 2^20 -- BASELINE configs[1]'s size -- (opt-in), with uneven
