@@ -67,3 +67,13 @@ def test_clock_sampler_never_fails_without_a_device(monkeypatch):
     assert set(out) >= {"source", "timed", "after"}
     for label in ("timed", "after"):
         assert out[label]["samples"] >= 0 and (out[label]["samples"] == 0) == (out[label]["sclk_mhz_median"] is None)
+
+
+def test_pmc_self_measurement_degrades_to_a_note(monkeypatch):
+    """bench.measure_pmc_traffic on a box without rocprofv3: no exception, no record, a note that says why (bench.py
+    then falls back to the stamped profiles/pmc_traffic.json when its library hash matches, or reports no traffic)."""
+    import argparse
+    import bench
+    monkeypatch.setenv("PATH", "/nonexistent")
+    rec, note = bench.measure_pmc_traffic(argparse.Namespace(workload="chain", window_bits=0, planes=0), 22)
+    assert rec is None and "rocprofv3" in note
