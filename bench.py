@@ -33,7 +33,7 @@ Other workloads / modes (BASELINE configs 2 and 5, the reference's own bench cir
                             written and re-read through the snarkjs .zkey format (read_zkey path)
   --workload poseidon       BASELINE configs[4]: a REAL Poseidon(2) hash chain, circomlib parameters (Grain LFSR,
                             t = 3, R_F = 8, R_P = 57; pinned to circomlibjs' KATs by oracle/poseidon_ref.py),
-                            243 S-box rows per hash with the linear layers folded into rows of up to 61
+                            240 S-box rows per hash with the linear layers folded into rows of up to 61
                             full-width terms (what circom --O2 leaves); R1CS not circom-compiled; key
                             through the .zkey format
   --workload poseidon-shaped  rounds 3-4's substitute: seeded constants, every lane materialised, 4-term rows
@@ -287,23 +287,25 @@ def poseidon_chain_circuit(cc, k, n_hashes=None):
     poseidon([1, 2]) = 0x115cc0f5...189a and the public output h_H is checked against the oracle's chain.
 
     The R1CS is NOT circom-compiled (no circom / snarkjs offline).  It is what a linear-substitution
-    optimiser (circom --O2) leaves of the round function: ONLY the S-box rows -- 81 S-boxes x 3 rows
-    (x2 = in*in, x4 = x2*x2, x5 = x4*in: circomlib's Sigma template) = 243 rows per hash -- with every
-    linear layer (round constants, MDS products) folded into the linear combination that feeds the next
+    optimiser (circom --O2) leaves of the round function: ONLY the S-box rows -- 80 S-boxes x 3 rows
+    (x2 = in*in, x4 = x2*x2, x5 = x4*in: circomlib's Sigma template) = 240 rows per hash, the constraint
+    count circomlib's Poseidon(2) is known for: the capacity lane enters round 0 as the constant 0 + c_0, so
+    its first S-box is a constant and folds away (81 S-boxes - 1) -- with every linear layer (round constants, MDS products) folded into the linear combination that feeds the next
     S-box.  The two lanes that skip the S-box in a partial round are never materialised, so the S-box
     input of partial round r is a combination of ~r + 4 wires with full-width coefficients: A rows carry
     up to 61 terms (9.3 per row on average), B rows 17.5 per row -- the width circomlib's Poseidon has
     after --O2 (the sparse-matrix factorisation of circomlib changes the coefficients, not this growth).
     The chain output is folded into the C side of the last S-box row (3 terms) as circom does for
-    `out <== lc`.  Wires: 0 = one, 1 = h_H (public), 2 = h_0, 3.. = x_i, then 243 wires per hash.
+    `out <== lc`.  Wires: 0 = one, 1 = h_H (public), 2 = h_0, 3.. = x_i, then 240 wires per hash.
 
-    k = log2 of the domain: H = (2^k - 2) // 243 hashes unless n_hashes is given (m = 243 H rows)."""
+    k = log2 of the domain: H = (2^k - 2) // 240 hashes unless n_hashes is given (m = 240 H rows)."""
     R = R_MOD
+    ROWS = 240
     t, r_f, r_p = 3, 8, 57
     rounds = r_f + r_p
     rc, M = poseidon_parameters(t, r_f, r_p)
-    H = n_hashes if n_hashes is not None else ((1 << k) - 2) // 243
-    assert H >= 1, "one Poseidon(2) permutation needs 243 rows: k >= 8"
+    H = n_hashes if n_hashes is not None else ((1 << k) - 2) // ROWS
+    assert H >= 1, "one Poseidon(2) permutation needs 240 rows: k >= 8"
 
     # ---- one hash as a template over symbolic wires ('s', q) own S-box wires, ('p', j) the three
     # last-round wires of the previous hash, ('h',) h_0, ('x',) the absorbed input, ('1',) the constant
@@ -324,6 +326,9 @@ def poseidon_chain_circuit(cc, k, n_hashes=None):
             order = ([2, 1, 0] if r == rounds - 1 else [0, 1, 2]) if full else [0]
             for i in order:
                 lc = {key: v for key, v in lanes[i].items() if v}
+                if set(lc) <= {('1',)}:              # constant input (lane 0 of round 0): the S-box folds away
+                    lanes[i] = {('1',): pow(lc.get(('1',), 0), 5, R)}
+                    continue
                 rows.append((lc, lc, ('s', q)))
                 rows.append(({('s', q): 1}, {('s', q): 1}, ('s', q + 1)))
                 rows.append(({('s', q + 1): 1}, lc, ('s', q + 2)))
@@ -337,13 +342,13 @@ def poseidon_chain_circuit(cc, k, n_hashes=None):
                         lc_scale_add(acc, lanes[j], M[i][j])
                     mixed.append(acc)
                 lanes = mixed
-        assert q == 243 and len(rows) == 243
-        # last round ran lanes 2, 1, 0: wires s234..236 = lane 2, s237..239 = lane 1, s240..242 = lane 0
+        assert q == ROWS and len(rows) == ROWS
+        # last round ran lanes 2, 1, 0: wires s231..233 = lane 2, s234..236 = lane 1, s237..239 = lane 0
         return rows
 
-    last_x5 = {0: 242, 1: 239, 2: 236}                # lane -> own wire index of its last-round x5
+    last_x5 = {0: 239, 1: 236, 2: 233}                # lane -> own wire index of its last-round x5
     x_base = 3
-    s_base = 3 + H                                    # hash i owns wires s_base + 243 i + q
+    s_base = 3 + H                                    # hash i owns wires s_base + ROWS i + q
 
     table, tindex = [1], {1: 0}
 
@@ -378,8 +383,8 @@ def poseidon_chain_circuit(cc, k, n_hashes=None):
             base = np.zeros((len(hs), 5), dtype=np.int64)
             base[:, 1] = 2
             base[:, 2] = x_base + hs
-            base[:, 3] = s_base + 243 * hs
-            base[:, 4] = s_base + 243 * (hs - 1)
+            base[:, 3] = s_base + ROWS * hs
+            base[:, 4] = s_base + ROWS * (hs - 1)
             col = off[None, :] + base[:, kind]
             out.append((rp, col.reshape(-1), np.tile(cf, len(hs)), nnz))
         return out
@@ -404,16 +409,16 @@ def poseidon_chain_circuit(cc, k, n_hashes=None):
 
     a_rp, a_col, a_cf = assemble(0)
     b_rp, b_col, b_cf = assemble(1)
-    m = 243 * H
-    out_own = s_base + 243 * (H - 1) + 242            # the wire the public output replaces
-    # C: row q of hash i defines wire s_base + 243 i + q; the very last row defines
+    m = ROWS * H
+    out_own = s_base + ROWS * (H - 1) + ROWS - 1       # the wire the public output replaces
+    # C: row q of hash i defines wire s_base + ROWS i + q; the very last row defines
     # x5 = (out - M01 b - M02 c) / M00 with b, c the last-round x5 wires of lanes 1, 2
     c_col = s_base + np.arange(m, dtype=np.int64)
     inv00 = pow(M[0][0], R - 2, R)
     c_cf = np.zeros(m, dtype=np.int64)
     c_rp = np.arange(m + 1, dtype=np.int64)
-    lb = s_base + 243 * (H - 1) + last_x5[1]
-    lc_ = s_base + 243 * (H - 1) + last_x5[2]
+    lb = s_base + ROWS * (H - 1) + last_x5[1]
+    lc_ = s_base + ROWS * (H - 1) + last_x5[2]
     c_col = np.concatenate([c_col[:m - 1], np.asarray([1, lb, lc_], dtype=np.int64)])
     c_cf = np.concatenate([c_cf[:m - 1], np.asarray([cid(inv00), cid((R - M[0][1]) * inv00 % R),
                                                       cid((R - M[0][2]) * inv00 % R)], dtype=np.int64)])
@@ -429,7 +434,7 @@ def poseidon_chain_circuit(cc, k, n_hashes=None):
         x = i + 2
         w[x_base + i] = x
         st = [0, h, x]
-        base = s_base + 243 * i
+        base = s_base + ROWS * i
         q = 0
         for r in range(rounds):
             st = [(st[j] + rc[r * t + j]) % R for j in range(t)]
@@ -439,6 +444,9 @@ def poseidon_chain_circuit(cc, k, n_hashes=None):
                 x2 = st[j] * st[j] % R
                 x4 = x2 * x2 % R
                 x5 = x4 * st[j] % R
+                if r == 0 and j == 0:                # (0 + c_0)^5: a constant, no wires
+                    st[j] = x5
+                    continue
                 if base + q + 2 < n_vars:
                     w[base + q], w[base + q + 1], w[base + q + 2] = x2, x4, x5
                 else:
@@ -824,7 +832,7 @@ def main():
         mats, (A, B, Cm), w_ints, n_vars = poseidon_chain_circuit(cc, k)
         desc = (f"Poseidon(2) hash chain (circomlib parameters: Grain-LFSR constants + Cauchy MDS, t = 3, R_F = 8, "
                 f"R_P = 57; KAT-pinned: h_1 = circomlibjs poseidon([1, 2])), R1CS NOT circom-compiled (no circom / snarkjs / "
-                f"ptau offline): {mats.num_constraints // 243} hashes x 243 S-box rows = {mats.num_constraints} "
+                f"ptau offline): {mats.num_constraints // 240} hashes x 240 S-box rows = {mats.num_constraints} "
                 f"constraints in the 2^{k} domain, {n_vars} wires, linear layers folded into rows of up to 61 "
                 f"full-width terms ({len(A.col) / mats.num_constraints:.1f} / {len(B.col) / mats.num_constraints:.1f} nnz per "
                 "A / B row), key through the snarkjs .zkey writer + read_zkey (Coefs path)")

@@ -681,9 +681,9 @@ def test_poseidon_shaped_2p20_through_zkey_vs_cpu_restatement(gpulib, tmp_path):
 def test_real_poseidon_chain_2p20_through_zkey_one_gpu_and_8_ranks(gpulib, tmp_path):
     """BASELINE configs[4] as far as it can be built offline: a REAL Poseidon(2) hash chain with
     circomlib's Grain-LFSR parameters (bench.poseidon_chain_circuit; the checker oracle/poseidon_ref.py is
-    pinned to circomlibjs' KATs) AT SIZE: 4315 hashes = 1 048 545 rows, 1 052 862 wires (more wires than
-    the 2^20 domain), 9.7 M / 18.4 M full-width coefficients in A / B (rows of up to 61 terms).  The
-    public output is the oracle chain's h_4315 and wire values include circomlibjs' poseidon([1, 2]);
+    pinned to circomlibjs' KATs) AT SIZE: 4369 hashes x 240 rows = 1 048 560 rows, 1 052 931 wires (more wires than
+    the 2^20 domain), 9.8 M / 18.5 M full-width coefficients in A / B (rows of up to 61 terms).  The
+    public output is the oracle chain's h_4369 and wire values include circomlibjs' poseidon([1, 2]);
     satisfiable (GPU constraint check); key through g16_zkey_write -> read_zkey (the Coefs path,
     src/zkey.rs:151-196); proof bytes == the CPU restatement's on ONE GPU and on 8 emulated ranks under
     BOTH cuts; pairing accepted for h_H, rejected for h_H + 1."""
@@ -694,8 +694,8 @@ def test_real_poseidon_chain_2p20_through_zkey_one_gpu_and_8_ranks(gpulib, tmp_p
     import bench
     k = 20
     mats0, (A, B, Cm), w_ints, n_vars = bench.poseidon_chain_circuit(cc, k)
-    n_hashes = mats0.num_constraints // 243
-    assert n_hashes == 4315 and n_vars > (1 << k) and int(np.diff(A.row_ptr).max()) == 61
+    n_hashes = mats0.num_constraints // 240
+    assert n_hashes == 4369 and n_vars > (1 << k) and int(np.diff(A.row_ptr).max()) == 61
     chain = poseidon_ref.hash_chain(1, [i + 2 for i in range(n_hashes)])
     assert chain[1] == poseidon_ref.KATS[(1, 2)] and w_ints[1] == chain[-1]
     circ = cc.CircomCircuit(type("R", (), dict(a=A, b=B, c=Cm, num_constraints=mats0.num_constraints,
