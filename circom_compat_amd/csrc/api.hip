@@ -65,8 +65,9 @@ int work1_batch(const MsmConfig& cw, uint32_t wr, bool sharded) {
 // arithmetic as the allocations in ctx_create_impl (MsmSort::bytes_for, msm_work_bytes).
 // own_w / own_h: false when the planes are borrowed from another ctx.
 size_t msm_state_bytes(const MsmConfig& cw, const MsmConfig& ch, uint32_t lw, uint32_t l_cnt, uint32_t lh,
-                       uint32_t wr, bool sharded, bool own_w, bool own_h) {
+                       uint32_t wr, bool sharded, bool own_w, bool own_h, bool view_w) {
   size_t b = 0;
+  if (view_w) b += MsmSort::view_bytes_for(lw, cw);  // the filtered view of the witness sort (sparse B queries)
   if (own_w) b += (size_t)cw.Pn * ((size_t)lw * (64 * 2 + 128) + (size_t)l_cnt * 64);
   if (own_h) b += (size_t)ch.Pn * lh * 64;
   b += MsmSort::bytes_for(lw, cw) + MsmSort::bytes_for(lh, ch);
@@ -87,7 +88,7 @@ size_t msm_state_bytes(const MsmConfig& cw, const MsmConfig& ch, uint32_t lw, ui
 // allocator granularity and the runtime's own needs.  Domains the reference accepts (n <= 2^27,
 // qap.rs:30-32,63-68) are refused for memory only when not even ONE plane per point fits.
 void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_t lh, uint32_t wr, bool sharded,
-                      bool own_w, bool own_h, MsmConfig* cw, MsmConfig* ch) {
+                      bool own_w, bool own_h, bool view_w, MsmConfig* cw, MsmConfig* ch) {
   if (own_w) *cw = msm_make_config(lw ? lw : 1, o.window_bits, o.planes);
   if (own_h) *ch = msm_make_config(lh ? lh : 1, o.window_bits, o.planes);
   if (o.planes > 0) return;  // the caller's choice: allocation failures are reported as such
@@ -97,7 +98,7 @@ void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_
   // memory is mostly taken -- the host framework's caching allocator, other ctxs -- still serves a small key)
   const size_t margin = std::min(((size_t)2 << 30) + fr / 50, fr / 4);
   const size_t budget = fr - margin;
-  if (msm_state_bytes(*cw, *ch, lw, l_cnt, lh, wr, sharded, own_w, own_h) <= budget) return;  // full planes fit
+  if (msm_state_bytes(*cw, *ch, lw, l_cnt, lh, wr, sharded, own_w, own_h, view_w) <= budget) return;  // full planes fit
   // the distinct (D, Pn) layouts of each side, most planes first
   auto layouts = [&](const MsmConfig& full, uint32_t len, bool own) {
     std::vector<MsmConfig> v{full};
@@ -112,7 +113,7 @@ void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_
   size_t best_bytes = 0;
   for (const MsmConfig& a : vw)
     for (const MsmConfig& b : vh) {
-      const size_t need = msm_state_bytes(a, b, lw, l_cnt, lh, wr, sharded, own_w, own_h);
+      const size_t need = msm_state_bytes(a, b, lw, l_cnt, lh, wr, sharded, own_w, own_h, view_w);
       if (need > budget) continue;
       const long score = 5L * a.D + b.D;
       if (best < 0 || score < best || (score == best && need > best_bytes)) {
@@ -681,19 +682,15 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
     const uint32_t l_cnt = c->w_hi > l_first ? c->w_hi - l_first : 0;
     if (lender) c->cfg_w = lender->cfg_w;
     if (lend_h) c->cfg_h = lender->cfg_h;
-    const bool sharded = c->world > 1 || c->dist_wm;
-    plan_msm_configs(o, lw, l_cnt, lh, wr, sharded, !lender, !lend_h, &c->cfg_w, &c->cfg_h);
-    c->sort_w.init(lw, c->cfg_w);
-    c->sort_w.set_shard(c->shard_buckets ? c->rank : 0, (int)wr);
-    // A and B1 are gathered by the same (scalar, digit, bucket) entries: interleaved point by point,
-    // one 128-byte line serves both (G16_NO_PAIR_AB=1: separate arrays, for A/B measurements)
-    static const bool no_pair = [] { const char* e = getenv("G16_NO_PAIR_AB"); return e && atoi(e) != 0; }();
-    // Sparse B queries: count the points at infinity of b_g1_query[1..] (b_g2_query has the same pattern:
-    // both are b_i(tau) times a generator).  From 1/8 of the wires on, the B2 MSM -- the G2 one, a third of
-    // a proof -- runs over a filtered view of the witness sort (ctx.h: sort_b): single-device proving ctxs
-    // of >= 2^15 wires; G16_SPARSE_B=0 / 1 (diagnostic, tested) overrides the rule.  B1 stays in the A | B1
-    // pair launch over the full sort (un-pairing it and reducing it on its own cost more launches than its
-    // third of additions is worth: profiles/r05_sparse_b_ab.txt).
+    // Sparse B queries: count the wires whose B points are BOTH the point at infinity (b_g1_query[1 + i] and
+    // b_g2_query[1 + i]: b_i(tau) times a generator each, so a well-formed key has the same pattern in both;
+    // a term is only dropped when both are -- a key with a finite G2 point beside an infinite G1 one keeps
+    // it, as the reference does, which reads both arrays as given).  From 1/8 of the wires on, the B2 MSM --
+    // the G2 one, a third of a proof -- runs over a filtered view of the witness sort (ctx.h: sort_b):
+    // single-device proving ctxs of >= 2^15 wires; G16_SPARSE_B=0 / 1 (diagnostic, tested) overrides the
+    // rule.  B1 stays in the A | B1 pair launch over the full sort (un-pairing it and reducing it on its own
+    // cost more launches than its third of additions is worth: profiles/r05_sparse_b_ab.txt).  Decided
+    // BEFORE the memory plan, which budgets the view's entries (MsmSort::view_bytes_for).
     if (lender) {
       c->sparse_b = lender->sparse_b && c->world == 1;
       c->keep_b = lender->keep_b;
@@ -702,11 +699,14 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
       std::vector<uint32_t> bits((lw + 31) / 32, 0u);
       uint32_t inf = 0;
       const uint8_t* b1 = key->b_g1_query + 64;
+      const uint8_t* b2 = key->b_g2_query + 128;
+      auto all_zero = [](const uint8_t* q, int n) {
+        for (int k = 0; k < n; ++k)
+          if (q[k]) return false;
+        return true;
+      };
       for (uint32_t i = 0; i < lw; ++i) {
-        const uint8_t* pnt = b1 + (size_t)i * 64;
-        bool zero = true;
-        for (int k = 0; k < 64 && zero; ++k) zero = pnt[k] == 0;
-        if (zero) ++inf;
+        if (all_zero(b1 + (size_t)i * 64, 64) && all_zero(b2 + (size_t)i * 128, 128)) ++inf;
         else bits[i >> 5] |= 1u << (i & 31);
       }
       c->b_inf_points = inf;
@@ -719,7 +719,24 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
         c->keep_b = c->keep_b_own.p;
       }
     }
-    if (c->sparse_b) c->sort_b.init_view(lw, c->cfg_w);
+    const bool sharded = c->world > 1 || c->dist_wm;
+    plan_msm_configs(o, lw, l_cnt, lh, wr, sharded, !lender, !lend_h, c->sparse_b, &c->cfg_w, &c->cfg_h);
+    c->sort_w.init(lw, c->cfg_w);
+    c->sort_w.set_shard(c->shard_buckets ? c->rank : 0, (int)wr);
+    // A and B1 are gathered by the same (scalar, digit, bucket) entries: interleaved point by point,
+    // one 128-byte line serves both (G16_NO_PAIR_AB=1: separate arrays, for A/B measurements)
+    static const bool no_pair = [] { const char* e = getenv("G16_NO_PAIR_AB"); return e && atoi(e) != 0; }();
+    if (c->sparse_b) {
+      // the view is an optimisation: a device that cannot hold it after all (a caller-fixed plane count
+      // bypasses the plan) proves over the shared sort instead
+      try {
+        c->sort_b.init_view(lw, c->cfg_w);
+      } catch (const HipError&) {
+        (void)hipGetLastError();
+        c->sort_b.release_view();
+        c->sparse_b = false;
+      }
+    }
     if (lender) {
       borrow(c->ptsA, lender->ptsA);
       borrow(c->ptsB1, lender->ptsB1);
@@ -772,9 +789,19 @@ g16_status ctx_create_impl(const g16_key_desc* key, const g16_csr* a, const g16_
         const bool small = lw <= TBL_MAX_POINTS && lh <= TBL_MAX_POINTS;
         if (o.fixed_tables > 0 && !fits)
           throw std::runtime_error("fixed_tables: the tables need " + std::to_string(need >> 20) + " MiB, more than a third of the free device memory");
-        if (o.fixed_tables > 0 || (small && fits))
-          c->tbl.build(key->a_query + 64, key->b_g1_query + 64, key->b_g2_query + 128,
-                       key->l_query + (size_t)(l_first - c->p) * 64, key->h_query, lw, l_first - c->w_lo, l_cnt, lh, s);
+        if (o.fixed_tables > 0 || (small && fits)) {
+          try {
+            c->tbl.build(key->a_query + 64, key->b_g1_query + 64, key->b_g2_query + 128,
+                         key->l_query + (size_t)(l_first - c->p) * 64, key->h_query, lw, l_first - c->w_lo, l_cnt, lh, s);
+          } catch (const HipError&) {
+            // automatic mode only: a device that runs out of memory while the tables are built (their
+            // temporaries are not in the one-third rule) keeps the bucket path; an explicit request fails
+            if (o.fixed_tables > 0) throw;
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(s);
+            c->tbl.release();
+          }
+        }
       }
     }
 

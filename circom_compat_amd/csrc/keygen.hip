@@ -39,13 +39,20 @@ __global__ void __launch_bounds__(256) k_powers(PowTable T, Fr scale, Fr* out, u
   out[i] = r;
 }
 
-__global__ void __launch_bounds__(256) k_spmv(CsrDev M, const Fr* x, Fr* out, uint32_t rows) {
+// out[i] = row i of M times x, storage form.  One thread per SHORT row; the long ones (the constant
+// wire's column of a transposed circom matrix holds a term per constraint that uses a constant: 10^5 ..
+// 10^6 terms, which one thread walked for 0.9 s on the 2^20 Poseidon chain) go through the row classes of
+// spmv.h.
+struct FrOut {
+  Fr* out;
+  __device__ __forceinline__ void put(uint32_t i, const Fr29* v) const { out[i] = v[0].to_mont256(); }
+};
+__global__ void __launch_bounds__(256) k_spmv(SpmvDev M, const Fr* x, FrOut out, uint32_t rows) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
-  Fr acc = Fr::zero();
-  const uint32_t e = M.rowptr[i + 1];
-  for (uint32_t j = M.rowptr[i]; j < e; ++j) acc = acc + x[M.col[j]] * M.val[j];
-  out[i] = acc;
+  if (!spmv_row_is_short(M, i)) return;
+  const Fr29 v = spmv_row_thread(M, x, i);
+  out.put(i, &v);
 }
 
 // k[i] = (beta u + alpha v + w) * (i < num_inputs ? 1/gamma : 1/delta)
@@ -202,9 +209,19 @@ g16_status g16_setup_create_ex(int device, const g16_csr* at, const g16_csr* bt,
       upload(bt, dB);
       upload(ct, dC);
       const uint32_t g = ceil_div(N, 256);
-      G16_LAUNCH(k_spmv, g, 256, 0, s, (CsrDev{dA.rowptr.p, dA.col.p, dA.val.p}), (const Fr*)L.p, uvw.p, N);
-      G16_LAUNCH(k_spmv, g, 256, 0, s, (CsrDev{dB.rowptr.p, dB.col.p, dB.val.p}), (const Fr*)L.p, uvw.p + N, N);
-      G16_LAUNCH(k_spmv, g, 256, 0, s, (CsrDev{dC.rowptr.p, dC.col.p, dC.val.p}), (const Fr*)L.p, uvw.p + 2 * (size_t)N, N);
+      const g16_csr* hm[3] = {at, bt, ct};
+      CsrStore* dm[3] = {&dA, &dB, &dC};
+      for (int q = 0; q < 3; ++q) {
+        spmv_cook(dm[q]->col.p, dm[q]->val.p, hm[q]->nnz, s);
+        SpmvPlan plan;
+        const uint32_t* rp = hm[q]->row_ptr;
+        plan.build(&rp, 1, N);
+        const SpmvMats<1> M{{SpmvDev{dm[q]->rowptr.p, dm[q]->col.p, dm[q]->val.p}}};
+        const FrOut out{uvw.p + (size_t)q * N};
+        G16_LAUNCH(k_spmv, g, 256, 0, s, M.m[0], (const Fr*)L.p, out, N);
+        spmv_run_long<1, FrOut>(plan, M, (const Fr*)L.p, out, s);
+        G16_HIP(hipStreamSynchronize(s));  // the plan's buffers are released at the end of this scope
+      }
       G16_LAUNCH(k_lin_scalars, g, 256, 0, s, (const Fr*)uvw.p, (const Fr*)(uvw.p + N),
                  (const Fr*)(uvw.p + 2 * (size_t)N), alpha, beta, ginv, dinv, num_inputs, N, lin.p);
       G16_HIP(hipDeviceSynchronize());

@@ -153,6 +153,11 @@ struct MsmSort {
   // circom key hold the point at infinity for every wire that appears in no B row: a third of the wires
   // of a Poseidon chain; the shared witness sort would spend a full G2 mixed addition on each.
   void init_view(uint32_t capacity, const MsmConfig& cfg);
+  void release_view() {  // a view whose allocation failed half way: back to the empty state
+    count.release(); offset.release(); cursor.release(); entries.release(); multi_l.release();
+    meta.release(); multi_l2.release(); meta2.release(); scan_tmp.release();
+    cap = len = 0;
+  }
   void run_view(const MsmSort& src, const uint32_t* keep_bits, hipStream_t stream);
   static size_t view_bytes_for(uint32_t capacity, const MsmConfig& cfg) {
     const uint64_t M = (uint64_t)capacity * cfg.W;

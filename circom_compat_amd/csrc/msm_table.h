@@ -71,6 +71,13 @@ struct TableSet {
   void build(const uint8_t* a, const uint8_t* b1, const uint8_t* b2, const uint8_t* l, const uint8_t* h,
              uint32_t len_w, uint32_t l_idx_min, uint32_t l_cnt, uint32_t len_h, hipStream_t stream);
   void borrow(const TableSet& lender);
+  void release() {  // a build that failed half way (automatic mode): no tables, the bucket path proves
+    oA.release(); oB1.release(); oL.release(); oH.release(); oB2.release();
+    part1.release(); partH.release(); part2.release();
+    tA = tB1 = tL = tH = nullptr;
+    tB2 = nullptr;
+    active = false;
+  }
   size_t table_bytes() const { return tbl_bytes((size_t)2 * len_w + l_cnt + len_h, len_w); }
 
   // A, B1, L, s*A, r*B1 over the witness (w1 = w_dev + 1: entry i pairs with w[1 + i])

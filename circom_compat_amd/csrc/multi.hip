@@ -188,6 +188,7 @@ struct Multi {
   // peer copy, microseconds of a 4 KiB there-and-back; [src * G + dst]
   std::vector<float> link_gbps, link_echo_us;
   size_t link_probe_bytes = 0;
+  bool links_probed = false;  // the probe runs on the first g16_multi_links call, not at create
   StageRunner pool;
 };
 
@@ -309,7 +310,8 @@ __global__ void __launch_bounds__(256) k_selftest_check(const int32_t* recv, int
 // What the links deliver, measured with the copies a proof makes (hipMemcpyPeerAsync from the source's
 // exchange buffer into the destination's, on the source's copy stream for that destination): one copy
 // of up to 64 MiB timed by events on that stream, and a 4 KiB copy there and back timed on the host.
-// One pair at a time, at create: the figures are the uncontended per-link rates that
+// One pair at a time, on the first g16_multi_links call (a measurement must neither lengthen nor be
+// able to fail the creation of a ctx that would otherwise work: its errors leave zeros): the figures are the uncontended per-link rates that
 // scripts/dist_projection.py assumes (48 GB/s per xGMI link) -- on the first multi-GPU box they are a
 // measurement instead (g16_multi_links; scripts/hardware_day.sh prints the table).
 void multi_link_probe(Multi& M) {
@@ -327,6 +329,7 @@ void multi_link_probe(Multi& M) {
     G16_HIP(hipEventCreate(&e0));
     G16_HIP(hipEventCreate(&e1));
     for (int b = 0; b < G; ++b) {
+      if (a == b) continue;  // no link to itself
       g16_ctx* cb = M.ch[b];
       hipStream_t cs = M.dv[a]->cs[b];
       // warm the path, then time one copy
@@ -465,7 +468,15 @@ g16_ctx* multi_child(g16_ctx* parent, int index) {
 }
 int multi_links(const g16_ctx* parent, float* gbps, float* echo_us, int cap, size_t* probe_bytes) {
   if (!parent || !parent->multi) return -1;
-  const Multi& M = *parent->multi;
+  Multi& M = *parent->multi;
+  if (!M.links_probed) {
+    M.links_probed = true;
+    try {
+      multi_link_probe(M);
+    } catch (const std::exception&) {  // a measurement: what could not be timed reads 0
+      (void)hipGetLastError();
+    }
+  }
   const int n = M.G * M.G;
   for (int i = 0; i < n && i < cap; ++i) {
     if (gbps) gbps[i] = i < (int)M.link_gbps.size() ? M.link_gbps[i] : 0.f;
@@ -592,7 +603,6 @@ g16_status multi_create(const g16_key_desc* key, const g16_csr* a, const g16_csr
       if (peer_state != 1)
         fprintf(stderr, "libg16_amd: %s -- the exchanges of every proof will be staged by the runtime\n", why.c_str());
       multi_selftest(*M);
-      multi_link_probe(*M);
     } catch (const std::exception& e) {
       code = G16_ERR_HIP;
       M->pool.first_error = e.what();

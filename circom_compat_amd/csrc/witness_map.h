@@ -3,6 +3,7 @@
 // ConstraintMatrices (src/zkey.rs:151-196): row-major sparse rows of (coeff, index).
 #pragma once
 #include "ntt29.h"
+#include "spmv.h"
 
 namespace g16 {
 
@@ -28,7 +29,8 @@ struct WitnessMap {
   Ntt29Plan plan;
   DevBuf<Fr> cs_lo, cs_hi, ci_lo, ci_hi;  // libsnark: coset tables g^j / n and g^-j / n (g = 5)
   Fr z_inv_packed;                        // libsnark: 1 / (g^n - 1), packed internal
-  CsrStore dA, dB;
+  CsrStore dA, dB;   // cooked (spmv.h): unit coefficients flagged in col, the others as c * 2^266
+  SpmvPlan spmv;     // row classes of (A, B): short rows in k_spmv_abc, longer ones in spmv.h's kernels
   DevBuf<int32_t> abc;  // a | b | c as limb planes (ntt29.h): [3][9][n] int32
 
   void init(const CsrHost& A, const CsrHost& B, uint32_t m, uint32_t num_inputs, int reduction = 0);

@@ -29,23 +29,33 @@ __device__ __forceinline__ Fr row_dot(const uint32_t* rowptr, const uint32_t* co
   return acc;
 }
 
-__global__ void __launch_bounds__(256) k_spmv_abc(CsrDev A, CsrDev B, const Fr* w, uint32_t m,
-                                                  uint32_t num_inputs, uint32_t n, int32_t* abc) {
+// a, b, c = a o b of one row into the NTT's limb planes
+struct AbcOut {
+  int32_t* abc;
+  uint32_t n;
+  __device__ __forceinline__ void put(uint32_t i, const Fr29* v) const {
+    const size_t vs = (size_t)NTT29_LIMBS * n;
+    store_planes(abc, n, i, v[0]);
+    store_planes(abc + vs, n, i, v[1]);
+    store_planes(abc + 2 * vs, n, i, v[0] * v[1]);
+  }
+};
+
+// Short rows (<= SPMV_SHORT terms in A and in B: what a chain of products or wire copies consists
+// of) and the rows past the matrices; medium and huge rows belong to spmv_run_long (spmv.h).
+__global__ void __launch_bounds__(256) k_spmv_abc(SpmvDev A, SpmvDev B, const Fr* w, uint32_t m,
+                                                  uint32_t num_inputs, uint32_t n, AbcOut out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fr ai = Fr::zero(), bi = Fr::zero(), ci = Fr::zero();
+  Fr29 v[2] = {Fr29::zero(), Fr29::zero()};
   if (i < m) {
-    ai = row_dot(A.rowptr, A.col, A.val, w, i);
-    bi = row_dot(B.rowptr, B.col, B.val, w, i);
-    ci = ai * bi;
+    if (!spmv_row_is_short(A, i) || !spmv_row_is_short(B, i)) return;
+    v[0] = spmv_row_thread(A, w, i);
+    v[1] = spmv_row_thread(B, w, i);
   } else if (i < m + num_inputs) {
-    ai = w[i - m];  // qap.rs:46-50
+    v[0] = Fr29::from_mont256(w[i - m]);  // qap.rs:46-50
   }
-  // hand over to the NTT in its own layout: lazy limbs, one plane per limb
-  const size_t vs = (size_t)NTT29_LIMBS * n;
-  store_planes(abc, n, i, Fr29::from_mont256(ai));
-  store_planes(abc + vs, n, i, Fr29::from_mont256(bi));
-  store_planes(abc + 2 * vs, n, i, Fr29::from_mont256(ci));
+  out.put(i, v);
 }
 
 // h = a * b - c (qap.rs:75,83-85), written as canonical integers and / or in the storage form
@@ -183,14 +193,19 @@ void WitnessMap::init(const CsrHost& A, const CsrHost& B, uint32_t m_, uint32_t 
   };
   up(A, dA);
   up(B, dB);
+  spmv_cook(dA.col.p, dA.val.p, A.nnz, nullptr);
+  spmv_cook(dB.col.p, dB.val.p, B.nnz, nullptr);
+  const uint32_t* rps[2] = {A.rowptr, B.rowptr};
+  spmv.build(rps, 2, m);
   abc.alloc((size_t)3 * NTT29_LIMBS * n);
 }
 
 void WitnessMap::run(const Fr* w_dev, U256* h_canon, Fr* h_mont, hipStream_t stream) {
-  CsrDev A{dA.rowptr.p, dA.col.p, dA.val.p};
-  CsrDev B{dB.rowptr.p, dB.col.p, dB.val.p};
+  const SpmvMats<2> M{{SpmvDev{dA.rowptr.p, dA.col.p, dA.val.p}, SpmvDev{dB.rowptr.p, dB.col.p, dB.val.p}}};
   const size_t vs = (size_t)NTT29_LIMBS * n;
-  G16_LAUNCH(k_spmv_abc, ceil_div(n, 256), 256, 0, stream, A, B, w_dev, m, num_inputs, n, abc.p);
+  const AbcOut out{abc.p, n};
+  G16_LAUNCH(k_spmv_abc, ceil_div(n, 256), 256, 0, stream, M.m[0], M.m[1], w_dev, m, num_inputs, n, out);
+  spmv_run_long<2, AbcOut>(spmv, M, w_dev, out, stream);
   if (reduction == 1) {
     // LibsnarkReduction::witness_map_from_matrices (ark-groth16; call sites reference
     // tests/groth16.rs:25-35): ifft, coset fft with g = 5, (a b - c) / Z, inverse coset fft

@@ -27,7 +27,8 @@ struct WmDist {
   int k = 0, k1 = 0, k2 = 0;
   uint32_t n1 = 0, n2 = 0, c2 = 0, r1 = 0;  // c2 = n2 / G columns, r1 = n1 / G rows per rank
   Ntt29Plan planN, plan1, plan2;            // planN: only its omega_n / omega_2n tables are used
-  CsrStore dA, dB;
+  CsrStore dA, dB;                          // cooked (spmv.h)
+  SpmvPlan spmv;                            // classes of this rank's rows
   DevBuf<int32_t> bufA;  // [3][c2][9][n1]
   DevBuf<int32_t> bufB;  // [3][r1][9][n2]
 

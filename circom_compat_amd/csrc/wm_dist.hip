@@ -6,21 +6,6 @@ namespace g16 {
 
 namespace {
 
-__device__ __forceinline__ Fr row_dot(const uint32_t* rowptr, const uint32_t* col, const Fr* val,
-                                      const Fr* w, uint32_t i) {
-  // evaluate_constraint (ark-groth16 r1cs_to_qap, called at qap.rs:42-43)
-  Fr acc = Fr::zero();
-  const uint32_t e = rowptr[i + 1];
-  const Fr one = Fr::one();
-  for (uint32_t j = rowptr[i]; j < e; ++j) {
-    Fr x = w[col[j]];
-    Fr cf = val[j];
-    if (cf != one) x = x * cf;
-    acc = acc + x;
-  }
-  return acc;
-}
-
 __device__ __forceinline__ Fr29 omega_pow(const Fr* tlo, const Fr* thi, int h1, uint32_t e) {
   const uint32_t l = e & ((1u << h1) - 1u);
   const uint32_t h = e >> h1;
@@ -38,25 +23,35 @@ struct DistGeom {
   int k, k1, k2, rank, world, h1;
 };
 
-// rows of this rank -> bufA[(v, i2l)][limb][i1]
-__global__ void __launch_bounds__(256) k_dist_spmv(CsrDev A, CsrDev B, const Fr* w, DistGeom G,
-                                                   int32_t* bufA) {
+// a, b, c = a o b of row i = i1 n2 + rank c2 + i2l of this rank -> bufA[(v, i2l)][limb][i1]
+struct DistAbcOut {
+  int32_t* bufA;
+  DistGeom G;
+  __device__ __forceinline__ void put(uint32_t i, const Fr29* v) const {
+    const uint32_t i1 = i / G.n2, i2l = i % G.n2 - (uint32_t)G.rank * G.c2;
+    const size_t vs = (size_t)NTT29_LIMBS * G.n1;
+    store_planes(bufA + ((size_t)0 * G.c2 + i2l) * vs, G.n1, i1, v[0]);
+    store_planes(bufA + ((size_t)1 * G.c2 + i2l) * vs, G.n1, i1, v[1]);
+    store_planes(bufA + ((size_t)2 * G.c2 + i2l) * vs, G.n1, i1, v[0] * v[1]);
+  }
+};
+
+// short rows of this rank and its rows past the matrices (the longer ones: spmv_run_long, spmv.h)
+__global__ void __launch_bounds__(256) k_dist_spmv(SpmvDev A, SpmvDev B, const Fr* w, DistGeom G,
+                                                   DistAbcOut out) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= G.c2 * G.n1) return;
   const uint32_t i2l = t / G.n1, i1 = t % G.n1;
   const uint32_t i = i1 * G.n2 + (uint32_t)G.rank * G.c2 + i2l;
-  Fr ai = Fr::zero(), bi = Fr::zero(), ci = Fr::zero();
+  Fr29 v[2] = {Fr29::zero(), Fr29::zero()};
   if (i < G.m) {
-    ai = row_dot(A.rowptr, A.col, A.val, w, i);
-    bi = row_dot(B.rowptr, B.col, B.val, w, i);
-    ci = ai * bi;
+    if (!spmv_row_is_short(A, i) || !spmv_row_is_short(B, i)) return;
+    v[0] = spmv_row_thread(A, w, i);
+    v[1] = spmv_row_thread(B, w, i);
   } else if (i < G.m + G.num_inputs) {
-    ai = w[i - G.m];  // qap.rs:46-50
+    v[0] = Fr29::from_mont256(w[i - G.m]);  // qap.rs:46-50
   }
-  const size_t vs = (size_t)NTT29_LIMBS * G.n1;
-  store_planes(bufA + ((size_t)0 * G.c2 + i2l) * vs, G.n1, i1, Fr29::from_mont256(ai));
-  store_planes(bufA + ((size_t)1 * G.c2 + i2l) * vs, G.n1, i1, Fr29::from_mont256(bi));
-  store_planes(bufA + ((size_t)2 * G.c2 + i2l) * vs, G.n1, i1, Fr29::from_mont256(ci));
+  out.put(i, v);
 }
 
 // bufA[(v, i2l)][.][p] * omega_n^(-i2 j1)  ->  send[d][v][pl][limb][i2l],  p = d r1 + pl, j1 = bitrev(p)
@@ -219,15 +214,21 @@ void WmDist::init(const CsrHost& A, const CsrHost& B, uint32_t m_, uint32_t num_
   };
   up(A, dA);
   up(B, dB);
+  spmv_cook(dA.col.p, dA.val.p, A.nnz, nullptr);
+  spmv_cook(dB.col.p, dB.val.p, B.nnz, nullptr);
+  const uint32_t* rps[2] = {A.rowptr, B.rowptr};
+  const uint32_t lo = (uint32_t)rank * c2, hi = lo + c2, mask = n2 - 1;
+  spmv.build(rps, 2, m, [=](uint32_t i) { return (i & mask) >= lo && (i & mask) < hi; });
   bufA.alloc(exchange_ints());
   bufB.alloc(exchange_ints());
 }
 
 void WmDist::phase1(const Fr* w_dev, int32_t* send, hipStream_t s) {
   const DistGeom G = geom(*this);
-  CsrDev A{dA.rowptr.p, dA.col.p, dA.val.p};
-  CsrDev B{dB.rowptr.p, dB.col.p, dB.val.p};
-  G16_LAUNCH(k_dist_spmv, ceil_div((uint64_t)c2 * n1, 256), 256, 0, s, A, B, w_dev, G, bufA.p);
+  const SpmvMats<2> M{{SpmvDev{dA.rowptr.p, dA.col.p, dA.val.p}, SpmvDev{dB.rowptr.p, dB.col.p, dB.val.p}}};
+  const DistAbcOut out{bufA.p, G};
+  G16_LAUNCH(k_dist_spmv, ceil_div((uint64_t)c2 * n1, 256), 256, 0, s, M.m[0], M.m[1], w_dev, G, out);
+  spmv_run_long<2, DistAbcOut>(spmv, M, w_dev, out, s);
   ntt29_dif(plan1, bufA.p, (size_t)NTT29_LIMBS * n1, 3 * (int)c2, /*inverse=*/true, NTT_FUSE_NONE, s);
   G16_LAUNCH(k_dist_pack1, ceil_div((uint64_t)3 * c2 * n1, 256), 256, 0, s, (const int32_t*)bufA.p, G,
              (const Fr*)planN.tlo[1].p, (const Fr*)planN.thi[1].p, send);

@@ -35,16 +35,43 @@ use ark_std::rand::Rng;
 use ark_std::UniformRand;
 
 /// The two entry points of `Groth16::<Bn254, CircomReduction>` that sit on the proving path, with the
-/// reference's argument meaning (benches/groth16.rs:52-60, src/zkey.rs:866).  The error type is
-/// `GpuError` (`Synthesis(SynthesisError)` for everything the CPU path can report, `Library(code,
-/// message)` for device failures; it implements `std::error::Error`, so `?` into `Box<dyn Error>` /
-/// `color_eyre::Result` -- what the reference's tests and README use -- keeps compiling).
+/// reference's argument meaning AND return type (benches/groth16.rs:52-60, src/zkey.rs:866:
+/// `Result<Proof<Bn254>, SynthesisError>`), so callers that use `?` into `SynthesisError` or match on it
+/// keep compiling.  A device failure has no `SynthesisError` variant: like the `R1CSToQAP` impl in
+/// reduction.rs, these log the library's status and message to stderr and return
+/// `SynthesisError::UnexpectedIdentity` (never `Unsatisfiable`).  The `try_*` variants return the typed
+/// `GpuError` (`Synthesis(..)` for everything the CPU path can report, `Library(code, message)` for
+/// device failures) for callers that want to tell the two apart.
 pub struct Groth16Gpu;
+
+/// the documented lossy conversion of the reference-shaped entry points
+fn to_synthesis(e: GpuError, site: &str) -> SynthesisError {
+    match e {
+        GpuError::Synthesis(s) => s,
+        GpuError::Library(code, msg) => {
+            eprintln!("ark-circom-amd: libg16_amd failed in {site} (status {code}): {msg}");
+            SynthesisError::UnexpectedIdentity
+        }
+    }
+}
 
 impl Groth16Gpu {
     /// `create_proof_with_reduction_and_matrices(&pk, r, s, &matrices, num_inputs, num_constraints,
     /// &full_assignment)`: `pk` and `matrices` are the ones `prover` was built from.
     pub fn create_proof_with_reduction_and_matrices(
+        prover: &mut GpuProver,
+        r: Fr,
+        s: Fr,
+        num_inputs: usize,
+        num_constraints: usize,
+        full_assignment: &[Fr],
+    ) -> Result<Proof<Bn254>, SynthesisError> {
+        Self::try_create_proof_with_reduction_and_matrices(prover, r, s, num_inputs, num_constraints, full_assignment)
+            .map_err(|e| to_synthesis(e, "create_proof_with_reduction_and_matrices"))
+    }
+
+    /// the same with the typed error
+    pub fn try_create_proof_with_reduction_and_matrices(
         prover: &mut GpuProver,
         r: Fr,
         s: Fr,
@@ -64,6 +91,15 @@ impl Groth16Gpu {
     /// `CircomBuilder::build` produces, builder.rs:84-85).  No `ConstraintSystem` is synthesised:
     /// the matrices were taken from the key file once.
     pub fn prove<R: Rng>(
+        prover: &mut GpuProver,
+        circuit: CircomCircuit<Fr>,
+        rng: &mut R,
+    ) -> Result<Proof<Bn254>, SynthesisError> {
+        Self::try_prove(prover, circuit, rng).map_err(|e| to_synthesis(e, "prove"))
+    }
+
+    /// the same with the typed error
+    pub fn try_prove<R: Rng>(
         prover: &mut GpuProver,
         circuit: CircomCircuit<Fr>,
         rng: &mut R,

@@ -43,10 +43,12 @@ impl From<SynthesisError> for GpuError {
         GpuError::Synthesis(e)
     }
 }
-// Deliberately NO `impl From<GpuError> for SynthesisError` (round 5): no SynthesisError variant means
-// "the device failed", and rounds 2-4 squeezed a HIP out-of-memory into `Unsatisfiable`.  Everything in
-// this crate that can meet a device failure returns `GpuError`; the one place that has to return
-// `SynthesisError` (the `R1CSToQAP` impl in reduction.rs) logs the library's message first.
+// Deliberately NO blanket `impl From<GpuError> for SynthesisError`: no SynthesisError variant means
+// "the device failed", and rounds 2-4 squeezed a HIP out-of-memory into `Unsatisfiable`.  The typed
+// entry points (`GpuProver::*`, `Groth16Gpu::try_*`) return `GpuError`; the places that keep the
+// reference's `SynthesisError` signature (`Groth16Gpu::{prove, create_proof_with_reduction_and_matrices}`
+// in lib.rs, the `R1CSToQAP` impl in reduction.rs) convert explicitly: they log the library's status and
+// message first and return `UnexpectedIdentity`.
 
 pub struct GpuProver {
     ctx: *mut ffi::g16_ctx,
