@@ -1379,7 +1379,7 @@ g16_status g16_check_satisfied(int device, const g16_csr* a, const g16_csr* b, c
   }
 }
 
-g16_status g16_debug_ntt(int device, uint64_t* data, int log_n, int inverse, int algo) {
+g16_status g16_fft_in_place(int device, uint64_t* data, int log_n, int inverse, int algo) {
   if (!data || log_n < 0) return fail(nullptr, G16_ERR_INVALID, "bad argument");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

@@ -1,6 +1,8 @@
 // bench_kernels.hip -- measurement-only kernels: the integer-ALU ceilings that bound the MSM and
 // NTT kernels.  v_mad_u64_u32 issue rate is not in the local CDNA4 guides, so
 // it is measured here; bench.py / scripts report MSM time against it next to the HBM roofline.
+// Compiled only into a measurement build (make EXTRA=-DG16_DEBUG_ABI): the product library does not export it.
+#ifdef G16_DEBUG_ABI
 #include "../../include/g16_amd.h"
 #include "common.h"
 #include "ec29.h"
@@ -117,3 +119,4 @@ extern "C" g16_status g16_debug_alu_bench(int device, int kind, uint32_t blocks,
     return G16_ERR_HIP;
   }
 }
+#endif  // G16_DEBUG_ABI

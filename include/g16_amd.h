@@ -308,18 +308,23 @@ typedef struct {
 g16_status g16_verify_batch(int device, const g16_vk_desc* vk, const uint8_t* proofs,
                             const uint64_t* public_inputs, uint32_t n_proofs, uint8_t* ok_out);
 
-/* ---- debug / parity entry points (tests) ----------------------------------------------------- */
-/* In-place size-2^log_n NTT of host data, natural order in and out (ark-poly fft_in_place /
- * ifft_in_place semantics).  algo 0: DIF kernels + bit-reversal; algo 1: bit-reversal + DIT
- * (saturated-limb kernels of ntt.hip, used by the key generator); algo 2 / 3: the same two
- * schedules on the lazy-limb kernels of ntt29.hip (the witness map's).                             */
-g16_status g16_debug_ntt(int device, uint64_t* data, int log_n, int inverse, int algo);
+/* ---- EvaluationDomain::fft_in_place / ifft_in_place ----------------------------- */
+/* ark-poly Radix2EvaluationDomain::{fft_in_place, ifft_in_place} as called from reference
+ * src/circom/qap.rs:60-61,72-73,79-81: in-place size-2^log_n transform of host data (Montgomery Fr),
+ * natural order in and out, 1/n folded into the inverse.  impl selects which of the library's two
+ * transform stacks runs it: 2 = the witness map's lazy-limb DIF kernels + bit reversal (ntt29.hip; the
+ * default a caller wants), 3 = bit reversal + its DIT kernels (forward only); 0 / 1 = the same two
+ * schedules on the saturated-limb kernels of ntt.hip, which the key generator uses.                */
+g16_status g16_fft_in_place(int device, uint64_t* data, int log_n, int inverse, int impl);
 
-/* Integer-ALU ceilings (measurement only): kind 0 = Fq Montgomery multiplications, 1 = raw
- * v_mad_u64_u32, 2 = G1 mixed additions (saturated limbs), 3 / 4 = G1 / G2 mixed additions on the lazy
- * limbs the MSM kernels use.  Returns elapsed seconds and the number of operations.                */
+#ifdef G16_DEBUG_ABI
+/* Measurement only, NOT part of the product library: compiled when the library is built with
+ * EXTRA=-DG16_DEBUG_ABI (scripts/alu_bench.py).  Integer-ALU ceilings: kind 0 = Fq Montgomery
+ * multiplications, 1 = raw v_mad_u64_u32, 2 = G1 mixed additions (saturated limbs), 3 / 4 = G1 / G2 mixed
+ * additions on the lazy limbs the MSM kernels use.  Returns elapsed seconds and the number of operations. */
 g16_status g16_debug_alu_bench(int device, int kind, uint32_t blocks, uint32_t iters,
                                double* seconds, double* ops);
+#endif
 
 /* ---- synthetic keys (not on the proving path) --------------------- */
 /* Trapdoor (known toxic waste) circom/snarkjs-style setup on the GPU: what

@@ -59,6 +59,12 @@ def set_threads(n):
     lib().g16cpu_set_threads(int(n))
 
 
+def set_msm_chunks(n):
+    """tasks per MSM window: 1 = one task per window (ark-ec's msm_bigint under rayon); n > 1 cuts every
+    window's bases into n chunks so that windows x n tasks keep all host threads busy (same result)"""
+    lib().g16cpu_set_msm_chunks(int(n))
+
+
 def max_threads():
     return lib().g16cpu_max_threads()
 

@@ -209,25 +209,38 @@ static void fq2_inv(fq2* r, const fq2* a) {
     int32_t* digits = (int32_t*)malloc((size_t)n * W * sizeof(int32_t));                           \
     _Pragma("omp parallel for schedule(static)")                                                   \
     for (size_t i = 0; i < n; ++i) make_digits(scalars + 4 * i, c, W, digits + i * W);             \
-    G##_jac* wsum = (G##_jac*)malloc((size_t)W * sizeof(G##_jac));                                 \
+    /* g_msm_chunks == 1: one task per window, as ark-ec's msm_bigint runs them (rayon over the     \
+     * windows).  > 1 (g16cpu_set_msm_chunks: bench.py's conservative "all cores" CPU column): every  \
+     * window's bases are cut into that many contiguous chunks, one task per (window, chunk) with its \
+     * own buckets, and the chunk sums of a window are added -- the same group element */             \
+    const int CH = g_msm_chunks > 1 ? g_msm_chunks : 1;                                            \
+    G##_jac* wsum = (G##_jac*)malloc((size_t)W * CH * sizeof(G##_jac));                            \
     _Pragma("omp parallel for schedule(dynamic, 1)")                                               \
-    for (int w = 0; w < W; ++w) {                                                                  \
+    for (int t = 0; t < W * CH; ++t) {                                                             \
+      const int w = t / CH, ch = t % CH;                                                           \
+      const size_t i_lo = n * (size_t)ch / CH, i_hi = n * (size_t)(ch + 1) / CH;                   \
       const size_t nb = (size_t)1 << (c - 1);                                                      \
       G##_jac* buckets = (G##_jac*)malloc(nb * sizeof(G##_jac));                                   \
       for (size_t b = 0; b < nb; ++b) G##_set_inf(&buckets[b]);                                    \
-      for (size_t i = 0; i < n; ++i) {                                                             \
+      for (size_t i = i_lo; i < i_hi; ++i) {                                                       \
         const int32_t d = digits[i * W + w];                                                       \
         if (d > 0) G##_madd(&buckets[d - 1], &bases[i]);                                           \
         else if (d < 0) { G##_aff nq; G##_neg_aff(&nq, &bases[i]); G##_madd(&buckets[-d - 1], &nq); } \
       }                                                                                            \
       G##_jac run, res; G##_set_inf(&run); G##_set_inf(&res);                                      \
       for (size_t b = nb; b-- > 0;) { G##_add(&run, &buckets[b]); G##_add(&res, &run); }           \
-      wsum[w] = res; free(buckets);                                                                \
+      wsum[t] = res; free(buckets);                                                                \
+    }                                                                                              \
+    for (int w = 0; w < W; ++w) {                                                                  \
+      for (int ch = 1; ch < CH; ++ch) G##_add(&wsum[w * CH], &wsum[w * CH + ch]);                  \
+      wsum[w] = wsum[w * CH];                                                                      \
     }                                                                                              \
     G##_jac total; G##_set_inf(&total);                                                            \
     for (int w = W - 1; w >= 1; --w) { G##_add(&total, &wsum[w]); for (int k = 0; k < c; ++k) G##_dbl(&total); } \
     G##_add(&total, &wsum[0]);                                                                     \
     *out = total; free(wsum); free(digits); }
+
+static int g_msm_chunks = 1;  /* G##_msm: tasks per window (1 = ark-ec's shape) */
 
 /* ark-ec make_digits: signed radix-2^c digits, carry folded into the next window */
 static void make_digits(const u64 s[4], int c, int W, int32_t* out) {
@@ -346,6 +359,8 @@ void g16cpu_set_threads(int n) {
   (void)n;
 #endif
 }
+/* chunks of bases per MSM window (see G##_msm); 1 restores the ark-ec shape */
+void g16cpu_set_msm_chunks(int n) { g_msm_chunks = n > 1 ? n : 1; }
 int g16cpu_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

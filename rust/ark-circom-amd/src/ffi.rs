@@ -2,7 +2,7 @@
 //! tests/test_rust_shim.py (repository root) parses this file and asserts that the set of
 //! functions and their arities equal the C headers'.
 #![allow(non_camel_case_types)]
-use std::os::raw::{c_char, c_double, c_float, c_int, c_void};
+use std::os::raw::{c_char, c_float, c_int, c_void};
 
 pub type g16_status = c_int;
 pub const G16_OK: g16_status = 0;
@@ -189,8 +189,7 @@ extern "C" {
     pub fn g16_witness_host_buffer(ctx: *mut g16_ctx) -> *mut c_void;
     pub fn g16_check_satisfied(device: c_int, a: *const g16_csr, b: *const g16_csr, c: *const g16_csr, num_constraints: u32, w: *const u64, n_vars: usize, first_unsatisfied: *mut i64) -> g16_status;
     pub fn g16_verify_batch(device: c_int, vk: *const g16_vk_desc, proofs: *const u8, public_inputs: *const u64, n_proofs: u32, ok_out: *mut u8) -> g16_status;
-    pub fn g16_debug_ntt(device: c_int, data: *mut u64, log_n: c_int, inverse: c_int, algo: c_int) -> g16_status;
-    pub fn g16_debug_alu_bench(device: c_int, kind: c_int, blocks: u32, iters: u32, seconds: *mut c_double, ops: *mut c_double) -> g16_status;
+    pub fn g16_fft_in_place(device: c_int, data: *mut u64, log_n: c_int, inverse: c_int, impl_: c_int) -> g16_status;
     pub fn g16_setup_create(device: c_int, at: *const g16_csr, bt: *const g16_csr, ct: *const g16_csr, n_vars: u32, n_public: u32, num_constraints: u32, toxic: *const u64, out: *mut *mut g16_setup) -> g16_status;
     pub fn g16_setup_create_ex(device: c_int, at: *const g16_csr, bt: *const g16_csr, ct: *const g16_csr, n_vars: u32, n_public: u32, num_constraints: u32, toxic: *const u64, reduction: c_int, out: *mut *mut g16_setup) -> g16_status;
     pub fn g16_setup_key(s: *mut g16_setup, key: *mut g16_key_desc, ic: *mut *const u8, ic_count: *mut u32, gamma_g2: *mut u8) -> g16_status;

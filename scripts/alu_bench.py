@@ -1,4 +1,8 @@
-"""integer-ALU ceilings on the GPU (v_mad_u64_u32, Fq mul, G1 madd) -> gpurun_out/alu_bench.json"""
+"""integer-ALU ceilings on the GPU (v_mad_u64_u32, Fq mul, G1 madd) -> gpurun_out/alu_bench.json
+
+Needs a measurement build of the library: make -C circom_compat_amd/csrc EXTRA=-DG16_DEBUG_ABI OUT=../libg16_amd_dbg.so
+BUILD=../../build/hip_dbg, then G16_AMD_LIB=circom_compat_amd/libg16_amd_dbg.so python scripts/alu_bench.py
+(the product library does not export g16_debug_alu_bench)."""
 import ctypes as C
 import json
 import os

@@ -12,10 +12,16 @@ import helpers as H
 
 pytestmark = pytest.mark.gpu
 
+# The driver gives the whole `-m gpu` suite 1200 s; round 5's took 665 s, 280 s of it in the two legs below
+# (2^24 on one GPU: 127 s; 2^25 capacity point: 155 s -- mostly the CPU restatement proving beside them).
+# They are opt-in (G16_TEST_LARGE=1, run by scripts/r6/final_a.sh and recorded under profiles/): the same sizes
+# are covered by the bench lines profiles/r0N_bench_k24_single_gpu.json / _chain25.json, which byte-compare too.
+LARGE = bool(os.environ.get("G16_TEST_LARGE"))
+
 
 def _ntt(lib, arr, k, inverse, algo):
     a = arr.copy()
-    lib.check(lib.g16_debug_ntt(0, a.ctypes.data, k, 1 if inverse else 0, algo))
+    lib.check(lib.g16_fft_in_place(0, a.ctypes.data, k, 1 if inverse else 0, algo))
     return a
 
 
@@ -251,7 +257,7 @@ def _vk_dict(pk):
                 ic=[o.g1_from_bytes(bytes(x)) for x in pk.vk.gamma_abc_g1])
 
 
-@pytest.mark.parametrize("k", [20, 22, 24])
+@pytest.mark.parametrize("k", [20, 22, pytest.param(24, marks=pytest.mark.skipif(not LARGE, reason="opt-in: G16_TEST_LARGE=1"))])
 def test_full_prove_headline_sizes_bytes_pairing_and_qap_identities(gpulib, k):
     """BASELINE configs 2 / 3 / 4 (the bench circuit at 2^20, the headline 2^22, and configs[3]'s 2^24
     circuit on ONE GPU: 84 GiB of point planes): ONE full prove through the C ABI is
@@ -332,6 +338,7 @@ def test_full_prove_headline_sizes_bytes_pairing_and_qap_identities(gpulib, k):
         multi.close()
 
 
+@pytest.mark.skipif(not LARGE, reason="opt-in: G16_TEST_LARGE=1")
 def test_capacity_point_2p25_on_one_gpu(gpulib):
     """One size above BASELINE's largest circuit: 2^25 constraints on ONE GPU -- the last size whose full
     point planes fit 288 GB (12 planes x 384 B x 2^25 = 154 GB), window c = 22.

@@ -20,7 +20,7 @@ import helpers as H
 def _ntt(lib, vals, inverse, algo):
     arr = H.fr_mont_arr(vals)
     k = len(vals).bit_length() - 1
-    st = lib.g16_debug_ntt(0, arr.ctypes.data, k, 1 if inverse else 0, algo)
+    st = lib.g16_fft_in_place(0, arr.ctypes.data, k, 1 if inverse else 0, algo)
     lib.check(st)
     return H.fr_from_mont_arr(arr)
 

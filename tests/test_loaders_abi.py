@@ -26,6 +26,7 @@ def test_library_exports_every_declared_symbol(gpulib):
     for hdr in ("g16_amd.h", "g16_loaders.h"):
         src = open(os.path.join(ROOT, "include", hdr)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"#ifdef G16_DEBUG_ABI.*?#endif", "", src, flags=re.S)   # measurement builds only: not in the product
         declared |= set(re.findall(r"\b(g16_[a-z0-9_]+)\s*\(", src))
     assert declared, "no declarations parsed"
     from circom_compat_amd import _binding
@@ -33,6 +34,10 @@ def test_library_exports_every_declared_symbol(gpulib):
     assert gpulib.missing == []
     for name in declared:
         assert hasattr(gpulib.L, name), name
+    # VERDICT r5 hygiene: nothing named g16_debug_* leaves the product library
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", gpulib.path], capture_output=True, text=True).stdout
+    assert "g16_debug_" not in syms
 
 
 def test_no_cpu_fallback(gpulib, golden):
@@ -46,7 +51,7 @@ def test_no_cpu_fallback(gpulib, golden):
         cc.Prover(pk, mats, lib=gpulib)
     assert e.value.status == 4 and "no CPU fallback" in str(e.value)
     arr = H.fr_mont_arr([1, 2, 3, 4])
-    assert gpulib.g16_debug_ntt(0, arr.ctypes.data, 2, 0, 0) == 4
+    assert gpulib.g16_fft_in_place(0, arr.ctypes.data, 2, 0, 0) == 4
 
 
 def test_package_does_not_touch_oracle_or_emulator():

@@ -170,6 +170,15 @@ def test_c_oracle_matches_python_oracle(golden):
     b2 = [p2[i % 4] for i in range(40)]
     sc = H.rand_fr(rng, 40)
     assert cpu_ref.msm_g2(H.g2_arr(b2), H.fr_mont_arr(sc)) == o.g2_to_bytes(o.G2.msm(b2, sc))
+    # the chunk-parallel shape of the "all cores" CPU column (bench.py cpu_baseline.value_all_cores): same elements
+    for chunks in (2, 7, 64):
+        cpu_ref.set_msm_chunks(chunks)
+        try:
+            assert cpu_ref.msm_g1(H.g1_arr(bases), H.fr_mont_arr(H.rand_fr(random.Random(5), 200))) == \
+                o.g1_to_bytes(o.G1.msm(bases, H.rand_fr(random.Random(5), 200))), chunks
+            assert cpu_ref.msm_g2(H.g2_arr(b2), H.fr_mont_arr(sc)) == o.g2_to_bytes(o.G2.msm(b2, sc)), chunks
+        finally:
+            cpu_ref.set_msm_chunks(1)
     cons, wit, nv, npub = H.squaring_chain(5)
     opk = o.trapdoor_setup(cons, nv, npub, 11, 22, 33, 44, 55)
     ar, br = o.matrices_from_r1cs(cons)

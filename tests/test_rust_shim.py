@@ -10,6 +10,7 @@ CRATE = os.path.join(ROOT, "rust", "ark-circom-amd")
 
 def _strip_c(text):
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"#ifdef G16_DEBUG_ABI.*?#endif", " ", text, flags=re.S)   # measurement builds only
     return re.sub(r"//[^\n]*", " ", text)
 
 
