@@ -595,6 +595,22 @@ class Prover:
                                                      _np_ptr(out)), self.ctx)
         return Proof(out.tobytes())
 
+    def attach_rccl(self, nccl_comm: int):
+        """hand the library an ncclComm_t the host created over the same ranks (g16_dist_attach_rccl): the
+        collectives of prove_dist() are then issued by the library itself"""
+        self.lib.check(self.lib.g16_dist_attach_rccl(self.ctx, C.c_void_p(nccl_comm)), self.ctx)
+
+    def rccl_ranks(self) -> int:
+        return int(self.lib.g16_dist_rccl_ranks(self.ctx))
+
+    def prove_dist(self, r, s, w_dev_ptr: int) -> Proof:
+        """one whole sharded proof of this rank through the attached communicator (g16_prove_dist)"""
+        rs = _as_fr([r, s], self.lib) if not isinstance(r, np.ndarray) else np.stack([r, s])
+        out = np.empty(B.G16_PROOF_BYTES, dtype=np.uint8)
+        self.lib.check(self.lib.g16_prove_dist(self.ctx, _np_ptr(rs[0:1]), _np_ptr(rs[1:2]), C.c_void_p(w_dev_ptr),
+                                               self.n_vars, _np_ptr(out)), self.ctx)
+        return Proof(out.tobytes())
+
     def set_profiling(self, on: bool):
         self.lib.check(self.lib.g16_set_profiling(self.ctx, 1 if on else 0), self.ctx)
 

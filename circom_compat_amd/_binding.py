@@ -97,7 +97,7 @@ ABI_SYMBOLS = [
     "g16_prove_dist_phase3", "g16_set_profiling", "g16_stage_times", "g16_stage_name", "g16_ctx_info", "g16_multi_links",
     "g16_witness_buffer", "g16_witness_upload", "g16_witness_host_buffer", "g16_ctx_create_multi", "g16_dist_set_exchange_stream",
     "g16_partial_buffer", "g16_gather_buffer", "g16_prove_finish_dev", "g16_witness_map_dev", "g16_msm_g1_dev",
-    "g16_msm_g2_dev", "g16_verify_batch", "g16_fft_in_place", "g16_check_satisfied", "g16_zkey_write",
+    "g16_msm_g2_dev", "g16_verify_batch", "g16_fft_in_place", "g16_dist_attach_rccl", "g16_dist_rccl_ranks", "g16_prove_dist", "g16_check_satisfied", "g16_zkey_write",
     "g16_setup_create", "g16_setup_create_ex", "g16_setup_destroy", "g16_setup_key",
     "g16_loader_last_error", "g16_zkey_open", "g16_zkey_open_mem", "g16_zkey_close",
     "g16_zkey_header_get", "g16_zkey_key", "g16_zkey_ic", "g16_zkey_matrices", "g16_r1cs_open",
@@ -167,6 +167,9 @@ class Library:
             "g16_gather_buffer": (vp, [vp]),
             "g16_prove_finish_dev": (C.c_int, [vp, vp, vp, vp]),
             "g16_fft_in_place": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int]),
+            "g16_dist_attach_rccl": (C.c_int, [vp, vp]),
+            "g16_dist_rccl_ranks": (C.c_int, [vp]),
+            "g16_prove_dist": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp]),
             "g16_check_satisfied": (C.c_int, [C.c_int, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr),
                                               C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_int64)]),
             "g16_zkey_write": (C.c_int, [C.c_char_p, C.POINTER(KeyDesc), vp, vp, C.POINTER(Csr),

@@ -132,6 +132,13 @@ void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_
   }
 }
 
+// G16_SCHED_R5=1 (diagnostic, A/B): the round-5 schedule -- witness map started beside the witness sort, the L
+// reduction and B's assembly of a mid-sized proof queued on the `red` stream behind each other
+inline bool sched_r5() {
+  static const bool v = [] { const char* e = getenv("G16_SCHED_R5"); return e && atoi(e) != 0; }();
+  return v;
+}
+
 void collect_times(g16_ctx* c) {
   if (c->timer.enabled) c->timer.collect(c->st_ms, c->st_cnt);
 }
@@ -228,12 +235,19 @@ void enqueue_witness_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 afte
     G16_HIP(hipEventRecord(c->ev_acc[1], s));
     G16_HIP(hipStreamWaitEvent(q, c->ev_acc[1], 0));
     msm_reduce<Fq2>(c->sort_for_b(), c->work2, 0, 1, &S->B2, q, tm, /*hidden=*/true);
+    // Round 6 (2^20 timeline, profiles/r06_timeline_k20.txt): B's assembly (fin_b, 0.25 ms on one lane) used to
+    // queue on `red` BEHIND the L reduction and ended 0.3 ms after the last reduction of the proof -- fin_final
+    // waited for it.  Now it follows the B2 reduction at once and the L reduction takes the side stream (idle
+    // since the variable-base products finished), so the three tails -- B, L, H -- run side by side.
+    const bool r5 = sched_r5();
+    hipStream_t ql = r5 ? q : c->side;
+    if (!r5) after_b2();
     msm_accumulate<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, s, tm, /*fixup=*/false);
     G16_HIP(hipEventRecord(c->ev_acc[2], s));
-    G16_HIP(hipStreamWaitEvent(q, c->ev_acc[2], 0));
-    msm_fixup<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, q, tm);
-    msm_reduce<Fq>(c->sort_w, c->work1, 2, 1, &S->L, q, tm, /*hidden=*/true);
-    after_b2();
+    G16_HIP(hipStreamWaitEvent(ql, c->ev_acc[2], 0));
+    msm_fixup<Fq>(c->sort_w, c->ptsL, c->l_idx_min, c->work1, 2, ql, tm);
+    msm_reduce<Fq>(c->sort_w, c->work1, 2, 1, &S->L, ql, tm, /*hidden=*/true);
+    if (r5) after_b2();
     G16_HIP(hipEventRecord(c->ev_b2, q));
     G16_HIP(hipStreamWaitEvent(c->side, c->ev_b2, 0));  // the side stream joins: one event to wait on
     G16_HIP(hipEventRecord(c->ev_side, c->side));
@@ -300,7 +314,14 @@ template <class Hook, class Hook2>
 void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 after_b2) {
   hipStream_t s = c->stream, x = c->overlap ? c->aux : c->stream;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
-  G16_HIP(hipEventRecord(c->ev_w, s));  // w is resident (upload enqueued on the main stream)
+  // Round 6: the witness sort goes FIRST and the witness map waits for it.  The high-priority aux stream's
+  // NTT passes used to take the chip from the sort kernels: at 2^20 the first accumulation started at 1.2 ms
+  // instead of 0.4 (profiles/r06_timeline_k20.txt) although h is not needed before the last MSM; started
+  // after the sort, the witness map runs underneath the A | B1 accumulation as it always did at 2^22.
+  // From 2^17 wires on (below, everything is latency and the map -> H chain is the longer one).
+  const bool sort_first = !sched_r5() && c->overlap && (c->w_hi - c->w_lo) >= (1u << 17);
+  if (sort_first) enqueue_witness_sort(c, w_dev);
+  G16_HIP(hipEventRecord(c->ev_w, s));  // w is resident (upload enqueued on the main stream) [and sorted]
   G16_HIP(hipStreamWaitEvent(x, c->ev_w, 0));
   int id = tm ? tm->begin(ST_WITNESS_MAP, x) : -1;
   c->wm.run(w_dev, c->h_canon.p, nullptr, x);
@@ -309,7 +330,7 @@ void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 after_b2) {
   c->sort_h.run(c->h_canon.p + c->h_lo, c->h_hi - c->h_lo, /*mont=*/false, x);
   if (tm) tm->end(id, x);
   G16_HIP(hipEventRecord(c->ev_h, x));
-  enqueue_witness_msms(c, w_dev, after_ab, after_b2);
+  enqueue_witness_msms(c, w_dev, after_ab, after_b2, /*sorted=*/sort_first);
   enqueue_h_msm(c);
 }
 
@@ -920,6 +941,10 @@ void g16_ctx_destroy(g16_ctx* c) {
   if (c->red) {
     (void)hipStreamSynchronize(c->red);
     (void)hipStreamDestroy(c->red);
+  }
+  if (c->xs_own) {  // g16_dist_attach_rccl (the communicator itself is the host's)
+    (void)hipStreamSynchronize(c->xs_own);
+    (void)hipStreamDestroy(c->xs_own);
   }
   if (c->ev_w) (void)hipEventDestroy(c->ev_w);
   if (c->ev_h) (void)hipEventDestroy(c->ev_h);

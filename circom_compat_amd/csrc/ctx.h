@@ -37,6 +37,12 @@ struct g16_ctx {
   // set, the phase calls order themselves against it with events instead of blocking the host
   hipStream_t xstream = nullptr;
   bool have_xstream = false;
+  // g16_dist_attach_rccl: the communicator of the host's RCCL (opaque ncclComm_t), its size, the library's own
+  // high-priority exchange stream and the two exchange buffers g16_prove_dist moves with ncclAllToAll
+  void* nccl_comm = nullptr;
+  int nccl_ranks = 0;
+  hipStream_t xs_own = nullptr;
+  g16::DevBuf<uint8_t> xsend, xrecv;
   std::string err;
 
   g16::WitnessMap wm;

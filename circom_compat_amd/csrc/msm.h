@@ -94,7 +94,12 @@ inline int msm_part_shift(uint32_t nb) {
 // after the last accumulation.  So hidden reductions keep the exposed width.
 inline uint32_t msm_red_chunk(const MsmConfig& cfg, uint32_t nbatch = 1, uint32_t world = 1, bool hidden = false) {
   (void)hidden;  // hidden reductions keep the exposed width: 65536 threads either way (measured above)
-  const uint32_t lanes_target = 65536u;
+  // G16_RED_LANES (experiment knob): threads the weighted reduction aims at
+  static const uint32_t lanes_target = [] {
+    const char* e = getenv("G16_RED_LANES");
+    const long v = e ? atol(e) : 0;
+    return (v >= 1024 && v <= (1L << 22)) ? (uint32_t)v : 65536u;
+  }();
   uint32_t ch = (uint32_t)(((uint64_t)nbatch * cfg.D * cfg.B) / ((uint64_t)lanes_target * (world ? world : 1)));
   if (ch < 1) ch = 1;
   if (ch > (uint32_t)MSM_RED_CHUNK) ch = (uint32_t)MSM_RED_CHUNK;

@@ -711,20 +711,25 @@ void msm_reduce(const MsmSort& s, MsmWork<F>& work, int first_slot, int nbatch, 
   const uint32_t cps = ceil_div(cfg.B, red_chunk);
   const uint32_t nchunks = cps * (uint32_t)cfg.D;
   if (nchunks > work.ncontrib) throw std::runtime_error("msm_reduce: contribution buffer too small");
+  // the scratch of slot k starts at k * (its per-slot size): reductions of DIFFERENT slots may run on different
+  // streams at the same time (round 6: the L reduction of a mid-sized proof runs on the side stream)
+  MsmAcc<F>* contrib = work.contrib.p + (size_t)first_slot * work.ncontrib;
+  MsmAcc<F>* bsum = work.bsum.p + (size_t)first_slot * 256 * work.sets;
+  MsmAcc<F>* wsum = work.wsum.p + (size_t)first_slot * work.sets;
   G16_LAUNCH((k_bucket_reduce<F>), dim3(ceil_div(nchunks, 64), nbatch), 64, 0, stream,
              (const MsmAcc<F>*)partial, (const uint32_t*)s.offset.p, nb, lanes, cfg.B, red_chunk,
-             cps, nchunks, work.contrib.p, (size_t)work.slots, rng);
+             cps, nchunks, contrib, (size_t)work.slots, rng);
   // two-level tree: cps contributions -> nblk block sums -> 1 per set
   uint32_t nblk = ceil_div(cps / (uint32_t)s.world, SUM_THREADS * 2);
   if (nblk > 256) nblk = 256;
   if (nblk < 1) nblk = 1;
   G16_LAUNCH((k_set_sum<F>), dim3((uint32_t)cfg.D * nblk, nbatch), SUM_THREADS,
-             SUM_THREADS * sizeof(MsmAcc<F>), stream, (const MsmAcc<F>*)work.contrib.p, cps, nblk,
-             work.bsum.p, (size_t)nchunks, (size_t)256 * work.sets, rng, red_chunk);
+             SUM_THREADS * sizeof(MsmAcc<F>), stream, (const MsmAcc<F>*)contrib, cps, nblk,
+             bsum, (size_t)nchunks, (size_t)256 * work.sets, rng, red_chunk);
   G16_LAUNCH((k_set_sum<F>), dim3((uint32_t)cfg.D, nbatch), SUM_THREADS,
-             SUM_THREADS * sizeof(MsmAcc<F>), stream, (const MsmAcc<F>*)work.bsum.p, nblk, 1u,
-             work.wsum.p, (size_t)256 * work.sets, (size_t)work.sets, (const uint32_t*)nullptr, 1u);
-  G16_LAUNCH((k_horner<F>), nbatch, 64, 0, stream, (const MsmAcc<F>*)work.wsum.p, work.sets, cfg.D,
+             SUM_THREADS * sizeof(MsmAcc<F>), stream, (const MsmAcc<F>*)bsum, nblk, 1u,
+             wsum, (size_t)256 * work.sets, (size_t)work.sets, (const uint32_t*)nullptr, 1u);
+  G16_LAUNCH((k_horner<F>), nbatch, 64, 0, stream, (const MsmAcc<F>*)wsum, work.sets, cfg.D,
              cfg.c, out_dev);
   if (tm) tm->end(id, stream);
 }

@@ -58,6 +58,13 @@ MsmConfig msm_make_config(size_t len, int c_override, int planes_override) {
   // 2^20 proof 11.7 -> 12.3 ms)
   if ((uint64_t)len * (uint64_t)cfg.W < (uint64_t)96 * MSM_ACC_BLOCKS * MSM_ACC_THREADS)
     cfg.lanes = (uint32_t)MSM_ACC_BLOCKS_G2 * MSM_ACC_THREADS;
+  // G2 segment count: HALF the workgroups (1024 x 128 lanes: exactly one round of the G2 kernel's one wave per
+  // SIMD) once a segment still holds >= 256 entries -- fewer partial sums per bucket for the reduction, fewer
+  // bucket crossings per lane.  Same box, 2^22, three alternating pairs (profiles/r06_g2_grid_ab.txt):
+  // 36.67 / 36.59 / 36.59 ms per proof at 2048 workgroups, 36.04 / 36.15 / 35.98 at 1024; at 2^20 (120 entries
+  // per segment at 1024) 11.61 against 11.84: the long segments are what pays.
+  if ((uint64_t)len * (uint64_t)cfg.W >= (uint64_t)256 * (MSM_ACC_BLOCKS_G2 / 2) * MSM_ACC_THREADS)
+    cfg.lanes2 = (uint32_t)(MSM_ACC_BLOCKS_G2 / 2) * MSM_ACC_THREADS;
   if (const char* e = getenv("G16_ACC_GRID")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 65536) cfg.lanes = (uint32_t)v * MSM_ACC_THREADS;

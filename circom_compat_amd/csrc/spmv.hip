@@ -35,6 +35,7 @@ void SpmvPlan::build(const uint32_t* const* rp, int nmat_, uint32_t rows_,
   nmat = nmat_;
   rows = rows_;
   std::vector<uint32_t> med, huge, off;
+  std::vector<uint32_t> med_len;
   std::vector<SpmvTask> tk;
   for (uint32_t i = 0; i < rows; ++i) {
     uint32_t longest = 0;
@@ -46,6 +47,9 @@ void SpmvPlan::build(const uint32_t* const* rp, int nmat_, uint32_t rows_,
     if (keep && !keep(i)) continue;
     if (longest <= SPMV_TASK_TERMS) {
       med.push_back(i);
+      uint32_t tot = 0;  // lane iterations of the row's group: what a wave runs is the maximum over its 16 rows
+      for (int q = 0; q < nmat; ++q) tot += (rp[q][i + 1] - rp[q][i] + SPMV_G - 1) / SPMV_G;
+      med_len.push_back(tot);
       continue;
     }
     huge.push_back(i);
@@ -58,6 +62,16 @@ void SpmvPlan::build(const uint32_t* const* rp, int nmat_, uint32_t rows_,
     }
   }
   off.push_back((uint32_t)tk.size());
+  {
+    // rows of equal trip count side by side (counting sort: trip counts are <= nmat * SPMV_LANE_TERMS): the
+    // Poseidon chain's 3- to 61-term rows otherwise run every wave at its longest row
+    const uint32_t kmax = (uint32_t)nmat * SPMV_LANE_TERMS + 1;
+    std::vector<uint32_t> start(kmax + 1, 0), sorted(med.size());
+    for (uint32_t l : med_len) ++start[l + 1];
+    for (uint32_t k = 0; k < kmax; ++k) start[k + 1] += start[k];
+    for (size_t j = 0; j < med.size(); ++j) sorted[start[med_len[j]]++] = med[j];
+    med.swap(sorted);
+  }
   n_med = (uint32_t)med.size();
   n_huge = (uint32_t)huge.size();
   n_tasks = (uint32_t)tk.size();

@@ -308,6 +308,23 @@ typedef struct {
 g16_status g16_verify_batch(int device, const g16_vk_desc* vk, const uint8_t* proofs,
                             const uint64_t* public_inputs, uint32_t n_proofs, uint8_t* ok_out);
 
+/* ---- RCCL inside the library (north_star: "a final RCCL all-reduce of partial bucket sums over xGMI") ---- */
+/* A host that is not PyTorch (the Rust shim) creates one per-rank ctx per process (g16_options.rank / world,
+ * dist_wm = 1) and ONE ncclComm_t over the same ranks with its own RCCL (ncclGetUniqueId / ncclCommInitRank),
+ * then hands it over: nccl_comm is that opaque handle.  The library resolves ncclAllToAll / ncclAllGather /
+ * ncclCommCount from the RCCL already loaded in the process (dlsym), else from librccl.so -- it does not link
+ * RCCL -- checks that the communicator has g16_options.world ranks, allocates the two exchange buffers and a
+ * high-priority exchange stream.  Afterwards g16_prove_dist is one whole sharded proof per rank:
+ *   phase 1 -> ncclAllToAll -> phase 2 -> ncclAllToAll -> phase 3 -> ncclAllGather of the 1 KiB records -> finish
+ * (the g16_prove_dist_phase* calls with the collectives in between, ordered by events: the host never blocks
+ * between phases).  Every rank returns the same 256 proof bytes.  EC addition is not an ncclRedOp: the
+ * "all-reduce of bucket sums" is this all-gather + a local sum of world records.
+ * g16_dist_rccl_ranks: ranks of the attached communicator, 0 when none is attached.                     */
+g16_status g16_dist_attach_rccl(g16_ctx* ctx, void* nccl_comm);
+int g16_dist_rccl_ranks(const g16_ctx* ctx);
+g16_status g16_prove_dist(g16_ctx* ctx, const uint64_t r[4], const uint64_t s[4], const void* w_dev,
+                          size_t n_vars, uint8_t proof_out[G16_PROOF_BYTES]);
+
 /* ---- EvaluationDomain::fft_in_place / ifft_in_place ----------------------------- */
 /* ark-poly Radix2EvaluationDomain::{fft_in_place, ifft_in_place} as called from reference
  * src/circom/qap.rs:60-61,72-73,79-81: in-place size-2^log_n transform of host data (Montgomery Fr),

@@ -65,6 +65,11 @@ def set_msm_chunks(n):
     lib().g16cpu_set_msm_chunks(int(n))
 
 
+def set_msm_window(c):
+    """window bits of every MSM (0 = ark-ec's ln-based choice)"""
+    lib().g16cpu_set_msm_window(int(c))
+
+
 def max_threads():
     return lib().g16cpu_max_threads()
 

@@ -205,6 +205,7 @@ static void fq2_inv(fq2* r, const fq2* a) {
     if (n == 0) { G##_set_inf(out); return; }                                                      \
     int c;                                                                                         \
     if (n < 32) c = 3; else { int lg = 0; while (((size_t)1 << lg) < n) ++lg; c = lg * 69 / 100 + 2; } \
+    if (g_msm_window > 1 && g_msm_window < 31) c = g_msm_window;  /* "all cores" column only */      \
     const int num_bits = 254, W = (num_bits + c - 1) / c;                                          \
     int32_t* digits = (int32_t*)malloc((size_t)n * W * sizeof(int32_t));                           \
     _Pragma("omp parallel for schedule(static)")                                                   \
@@ -241,6 +242,7 @@ static void fq2_inv(fq2* r, const fq2* a) {
     *out = total; free(wsum); free(digits); }
 
 static int g_msm_chunks = 1;  /* G##_msm: tasks per window (1 = ark-ec's shape) */
+static int g_msm_window = 0;  /* G##_msm: window bits (0 = ark-ec's ln-based choice) */
 
 /* ark-ec make_digits: signed radix-2^c digits, carry folded into the next window */
 static void make_digits(const u64 s[4], int c, int W, int32_t* out) {
@@ -361,6 +363,9 @@ void g16cpu_set_threads(int n) {
 }
 /* chunks of bases per MSM window (see G##_msm); 1 restores the ark-ec shape */
 void g16cpu_set_msm_chunks(int n) { g_msm_chunks = n > 1 ? n : 1; }
+/* window bits of every MSM (0 restores ark-ec's choice): smaller windows keep a task's buckets in its core's
+ * cache when all host threads run MSM tasks at once (2^16 buckets x 96 B x 128 threads does not) */
+void g16cpu_set_msm_window(int c) { g_msm_window = c; }
 int g16cpu_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -189,6 +189,9 @@ extern "C" {
     pub fn g16_witness_host_buffer(ctx: *mut g16_ctx) -> *mut c_void;
     pub fn g16_check_satisfied(device: c_int, a: *const g16_csr, b: *const g16_csr, c: *const g16_csr, num_constraints: u32, w: *const u64, n_vars: usize, first_unsatisfied: *mut i64) -> g16_status;
     pub fn g16_verify_batch(device: c_int, vk: *const g16_vk_desc, proofs: *const u8, public_inputs: *const u64, n_proofs: u32, ok_out: *mut u8) -> g16_status;
+    pub fn g16_dist_attach_rccl(ctx: *mut g16_ctx, nccl_comm: *mut c_void) -> g16_status;
+    pub fn g16_dist_rccl_ranks(ctx: *const g16_ctx) -> c_int;
+    pub fn g16_prove_dist(ctx: *mut g16_ctx, r: *const u64, s: *const u64, w_dev: *const c_void, n_vars: usize, proof_out: *mut u8) -> g16_status;
     pub fn g16_fft_in_place(device: c_int, data: *mut u64, log_n: c_int, inverse: c_int, impl_: c_int) -> g16_status;
     pub fn g16_setup_create(device: c_int, at: *const g16_csr, bt: *const g16_csr, ct: *const g16_csr, n_vars: u32, n_public: u32, num_constraints: u32, toxic: *const u64, out: *mut *mut g16_setup) -> g16_status;
     pub fn g16_setup_create_ex(device: c_int, at: *const g16_csr, bt: *const g16_csr, ct: *const g16_csr, n_vars: u32, n_public: u32, num_constraints: u32, toxic: *const u64, reduction: c_int, out: *mut *mut g16_setup) -> g16_status;

@@ -107,6 +107,75 @@ impl GpuProver {
         reduction: Reduction,
         shard: Shard,
     ) -> Result<Self, GpuError> {
+        let ids: Vec<c_int> = devices.iter().map(|d| *d as c_int).collect();
+        Self::create_with(pk, matrices, reduction, shard, |opt| opt, |key, va, vb, m, opt, ctx| unsafe {
+            ffi::g16_ctx_create_multi(key, va, vb, m, ids.as_ptr(), ids.len() as c_int, opt, ctx)
+        })
+    }
+
+    /// One RANK of a prover sharded over `world` processes, one GPU each, with the collectives issued by
+    /// the library through RCCL (`g16_dist_attach_rccl`, include/g16_amd.h): `nccl_comm` is the
+    /// `ncclComm_t` this process created over the same `world` ranks with its own RCCL binding
+    /// (ncclGetUniqueId on rank 0, the id shared by the host's own means, ncclCommInitRank everywhere).
+    /// `prove_dist` is then one whole proof per rank: every rank gets the same `Proof`.
+    ///
+    /// # Safety
+    /// `nccl_comm` must be a live communicator of exactly `world` ranks in which this process is `rank`,
+    /// created on `device`; it must outlive the prover (the library never destroys it).
+    pub unsafe fn with_rccl(
+        pk: &ProvingKey<Bn254>,
+        matrices: &ConstraintMatrices<Fr>,
+        device: i32,
+        rank: i32,
+        world: i32,
+        nccl_comm: *mut std::os::raw::c_void,
+        shard: Shard,
+    ) -> Result<Self, GpuError> {
+        let me = Self::create_with(
+            pk,
+            matrices,
+            Reduction::Circom,
+            shard,
+            |mut opt| {
+                opt.device = device as c_int;
+                opt.rank = rank as c_int;
+                opt.world = world as c_int;
+                opt.dist_wm = 1;
+                opt
+            },
+            |key, va, vb, m, opt, ctx| unsafe { ffi::g16_ctx_create(key, va, vb, m, opt, ctx) },
+        )?;
+        check(me.ctx, ffi::g16_dist_attach_rccl(me.ctx, nccl_comm))?;
+        Ok(me)
+    }
+
+    /// ranks of the attached communicator (0: none)
+    pub fn rccl_ranks(&self) -> usize {
+        unsafe { ffi::g16_dist_rccl_ranks(self.ctx) as usize }
+    }
+
+    /// One sharded proof of this rank (`g16_prove_dist`): phase 1 -> ncclAllToAll -> phase 2 -> ncclAllToAll ->
+    /// phase 3 -> ncclAllGather of the 1 KiB records -> finish.  `w_dev`: the full assignment in device
+    /// memory (`4 * n_vars` u64, Montgomery), e.g. `g16_witness_buffer` after `g16_witness_upload`.
+    ///
+    /// # Safety
+    /// `w_dev` must point at `n_vars` field elements in the memory of this prover's device.
+    pub unsafe fn prove_dist(&mut self, r: Fr, s: Fr, w_dev: *const std::os::raw::c_void) -> Result<Proof<Bn254>, GpuError> {
+        let mut raw = [0u8; ffi::G16_PROOF_BYTES];
+        let (rw, sw) = (pack::fr_words(&r), pack::fr_words(&s));
+        check(self.ctx, ffi::g16_prove_dist(self.ctx, rw.as_ptr(), sw.as_ptr(), w_dev, self.n_vars, raw.as_mut_ptr()))?;
+        Ok(pack::unpack_proof(&raw))
+    }
+
+    /// packs the key and the matrices once and hands them to `make` (g16_ctx_create / _multi)
+    fn create_with(
+        pk: &ProvingKey<Bn254>,
+        matrices: &ConstraintMatrices<Fr>,
+        reduction: Reduction,
+        shard: Shard,
+        tune: impl FnOnce(ffi::g16_options) -> ffi::g16_options,
+        make: impl FnOnce(&ffi::g16_key_desc, &ffi::g16_csr, &ffi::g16_csr, u32, &ffi::g16_options, &mut *mut ffi::g16_ctx) -> c_int,
+    ) -> Result<Self, GpuError> {
         let n_vars = pk.a_query.len();
         let n_public = pk.vk.gamma_abc_g1.len() - 1;
         let a = pack::pack_g1_vec(&pk.a_query);
@@ -140,7 +209,7 @@ impl GpuProver {
         pack::pack_g2(&pk.vk.delta_g2, &mut key.delta_g2);
         let (ca, cb): (Csr, Csr) = pack::matrices_to_csr(matrices);
         let (va, vb) = (ca.view(), cb.view());
-        let opt = ffi::g16_options {
+        let opt = tune(ffi::g16_options {
             reduction: if reduction == Reduction::Libsnark { ffi::G16_REDUCTION_LIBSNARK } else { ffi::G16_REDUCTION_CIRCOM },
             shard: match shard {
                 Shard::Auto => ffi::G16_SHARD_AUTO,
@@ -148,12 +217,9 @@ impl GpuProver {
                 Shard::Buckets => ffi::G16_SHARD_BUCKETS,
             },
             ..Default::default()
-        };
+        });
         let mut ctx: *mut ffi::g16_ctx = std::ptr::null_mut();
-        let ids: Vec<c_int> = devices.iter().map(|d| *d as c_int).collect();
-        let st = unsafe {
-            ffi::g16_ctx_create_multi(&key, &va, &vb, matrices.num_constraints as u32, ids.as_ptr(), ids.len() as c_int, &opt, &mut ctx)
-        };
+        let st = make(&key, &va, &vb, matrices.num_constraints as u32, &opt, &mut ctx);
         check(std::ptr::null(), st)?;
         Ok(GpuProver { ctx, n_vars, num_inputs: matrices.num_instance_variables, num_constraints: matrices.num_constraints })
     }
