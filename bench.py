@@ -1307,6 +1307,12 @@ def main():
                 # threads do not); the fastest on a 2^18 probe is timed on the sample's own inputs
                 cands = [(0, max(2, -(-T // nw))), (0, 2), (0, 4)]
                 cands += [(c_, max(1, -(-T // (-(-254 // c_))))) for c_ in (12, 13, 14, 15)]
+                # the shape ark-ec 0.5's msm_bigint_wnaf_parallel is RECALLED to have (the crate is not vendored:
+                # unverifiable offline): threads / 2 chunks of bases, every chunk a window-parallel MSM with the
+                # window of ITS size, the chunk sums added
+                ch_ark = max(1, T // 2)
+                n_ch = max(32, -(-max(m_prev, 2) // ch_ark))
+                cands.append(((n_ch - 1).bit_length() * 69 // 100 + 2, ch_ark))
                 pk_p, mats_p, wc_p, _ = small_case(min(18, k))
                 probe = []
                 for c_, ch_ in cands:

@@ -132,8 +132,8 @@ void plan_msm_configs(const g16_options& o, uint32_t lw, uint32_t l_cnt, uint32_
   }
 }
 
-// G16_SCHED_R5=1 (diagnostic, A/B): the round-5 schedule -- witness map started beside the witness sort, the L
-// reduction and B's assembly of a mid-sized proof queued on the `red` stream behind each other
+// G16_SCHED_R5=1 (diagnostic, A/B): the round-5 schedule -- witness map always started beside the witness sort, the
+// L reduction and B's assembly of a mid-sized proof queued on the `red` stream behind each other
 inline bool sched_r5() {
   static const bool v = [] { const char* e = getenv("G16_SCHED_R5"); return e && atoi(e) != 0; }();
   return v;
@@ -314,12 +314,15 @@ template <class Hook, class Hook2>
 void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 after_b2) {
   hipStream_t s = c->stream, x = c->overlap ? c->aux : c->stream;
   StageTimer* tm = c->timer.enabled ? &c->timer : nullptr;
-  // Round 6: the witness sort goes FIRST and the witness map waits for it.  The high-priority aux stream's
-  // NTT passes used to take the chip from the sort kernels: at 2^20 the first accumulation started at 1.2 ms
-  // instead of 0.4 (profiles/r06_timeline_k20.txt) although h is not needed before the last MSM; started
-  // after the sort, the witness map runs underneath the A | B1 accumulation as it always did at 2^22.
-  // From 2^17 wires on (below, everything is latency and the map -> H chain is the longer one).
-  const bool sort_first = !sched_r5() && c->overlap && (c->w_hi - c->w_lo) >= (1u << 17);
+  // Round 6: with LARGE bucket sets (>= 2^18: 2^21-constraint proofs and up, the reductions stay on the main
+  // stream) the witness sort goes FIRST and the witness map waits for it -- the high-priority aux stream's NTT
+  // passes otherwise take the chip from the sort kernels and the first accumulation starts later; h is not needed
+  // before the last MSM.  Same box, map first / sort first (profiles/r06_schedule_ab.txt): 2^22 36.47, 36.30 /
+  // 35.79, 36.11 ms; 2^21 equal.  Mid-sized proofs keep the map first: behind the sort it runs wholly under the
+  // accumulations and costs them more than the earlier start returns (2^19 6.6 / 6.9, 2^20 11.2 / 11.4, Poseidon
+  // 2^20 10.9 / 11.2 ms).
+  const uint32_t nb_eff = c->cfg_w.nb() / (c->shard_buckets ? (uint32_t)c->world : 1u);
+  const bool sort_first = !sched_r5() && c->overlap && c->world == 1 && nb_eff >= (1u << 18);
   if (sort_first) enqueue_witness_sort(c, w_dev);
   G16_HIP(hipEventRecord(c->ev_w, s));  // w is resident (upload enqueued on the main stream) [and sorted]
   G16_HIP(hipStreamWaitEvent(x, c->ev_w, 0));

@@ -91,16 +91,16 @@ inline int msm_part_shift(uint32_t nb) {
 // on that one stream and the variable-base products wait for the first of them.  Measured on one box
 // (scripts/gpu_r3_run13.sh; 2^20 proof / one rank of 8 at 2^22, ms): 65536 threads 11.4-11.8 / 7.8-8.0,
 // 16384 threads 11.5-11.9 / 7.7-8.1, 8192 threads 12.4-12.5 / 8.9-9.1 -- the narrow reductions finish
-// after the last accumulation.  So hidden reductions keep the exposed width.
+// after the last accumulation (round 3's schedule; round 6 re-measured below).
 inline uint32_t msm_red_chunk(const MsmConfig& cfg, uint32_t nbatch = 1, uint32_t world = 1, bool hidden = false) {
-  (void)hidden;  // hidden reductions keep the exposed width: 65536 threads either way (measured above)
-  // G16_RED_LANES (experiment knob): threads the weighted reduction aims at
-  static const uint32_t lanes_target = [] {
-    const char* e = getenv("G16_RED_LANES");
-    const long v = e ? atol(e) : 0;
-    return (v >= 1024 && v <= (1L << 22)) ? (uint32_t)v : 65536u;
-  }();
-  uint32_t ch = (uint32_t)(((uint64_t)nbatch * cfg.D * cfg.B) / ((uint64_t)lanes_target * (world ? world : 1)));
+  // Hidden reductions (red / side streams, underneath an accumulation): HALF the exposed width.  Round 3 measured
+  // 65536 against 16384 threads as a tie; with round 6's schedule, same box (profiles/r06_schedule_ab.txt, block
+  // 3), 65536 / 32768 / 16384 threads: 2^19 6.77 / 6.35 / 6.53 ms, 2^20 11.44 / 11.07 / 10.97, dense-skewed 2^20 7.27 /
+  // 7.11 / 7.44, 2^18 4.51 / 4.50 / 4.61 -- the narrower launch takes fewer issue slots from the accumulation it
+  // hides under and still finishes before it.  Exposed reductions keep 65536 (2^22: 35.45 ms; 131072: 36.18;
+  // 32768: 36.90).
+  const uint32_t target = hidden ? 32768u : 65536u;
+  uint32_t ch = (uint32_t)(((uint64_t)nbatch * cfg.D * cfg.B) / ((uint64_t)target * (world ? world : 1)));
   if (ch < 1) ch = 1;
   if (ch > (uint32_t)MSM_RED_CHUNK) ch = (uint32_t)MSM_RED_CHUNK;
   if (world > 1) {  // largest power of two <= ch, <= 2^(partition shift)

@@ -17,7 +17,7 @@ PY
 ab() { # name, bench args
   for rep in 1 2; do
   for k in 1 0; do
-    G16_SCHED_R5=$k G16_BENCH_NO_PIPELINE=1 python bench.py $2 --no-pmc --cpu-log2 0 > $O/$1_r5$k_$rep.json 2> $O/err.txt; line $O/$1_r5$k_$rep.json "$1 sched_r5=$k"
+    G16_SCHED_R5=$k G16_BENCH_NO_PIPELINE=1 python bench.py $2 --no-pmc --cpu-log2 0 > $O/${1}_r5${k}_${rep}.json 2> $O/err.txt; line $O/${1}_r5${k}_${rep}.json "$1 sched_r5=$k"
   done
   done
 }
