@@ -52,6 +52,27 @@ G16_HD int32_t opaque(int32_t x) {
   return x;
 }
 
+// F29_CHAIN_MAD (round 6 experiment, variant builds only): every limb product of mul / mul2 / sqr as an inline-asm
+// v_mad_i64_i32 whose addend is the running column sum, so that the carry of column k is the FIRST addend of column
+// k + 1.  Left to itself LLVM sums every column from zero (17 independent chains) and adds the carry afterwards with a
+// v_lshl_add_u64: 17 extra half-rate instructions per product, ~7 % of the accumulation kernels' issue slots -- at
+// the price of making a product ONE dependent chain of 171 multiply-adds (scripts/ubench/fqmul_chain.hip).
+#if defined(F29_CHAIN_MAD) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mad_vv(int64_t& acc, int32_t a, int32_t b) {
+  uint64_t sd;
+  asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(sd) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mad_vs(int64_t& acc, int32_t a, int32_t b) {  // b: a compile-time constant (modulus limb)
+  uint64_t sd;
+  asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(sd) : "v"(a), "s"(b));
+}
+#define F29_MAD(acc, a, b) ::g16::f29::mad_vv(acc, a, b)
+#define F29_MAD_C(acc, a, b) ::g16::f29::mad_vs(acc, a, (int32_t)(b))
+#else
+#define F29_MAD(acc, a, b) acc += (int64_t)(a) * (int64_t)(b)
+#define F29_MAD_C(acc, a, b) acc += (int64_t)(a) * (int64_t)(b)
+#endif
+
 struct W8 {
   uint32_t v[8];
 };
@@ -214,19 +235,19 @@ struct F29 {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
-      for (int i = 0; i <= k; ++i) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
+      for (int i = 0; i <= k; ++i) F29_MAD(acc, a.l[i], b.l[k - i]);
 #pragma unroll
-      for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * (int64_t)C::MOD.v[k - i];
+      for (int i = 0; i < k; ++i) F29_MAD_C(acc, m[i], C::MOD.v[k - i]);
       m[k] = (int32_t)(((uint32_t)acc * C::NINV) & f29::MASK);
-      acc += (int64_t)m[k] * (int64_t)C::MOD.v[0];
+      F29_MAD_C(acc, m[k], C::MOD.v[0]);
       acc >>= 29;
     }
 #pragma unroll
     for (int k = N; k < 2 * N - 1; ++k) {
 #pragma unroll
-      for (int i = k - N + 1; i < N; ++i) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
+      for (int i = k - N + 1; i < N; ++i) F29_MAD(acc, a.l[i], b.l[k - i]);
 #pragma unroll
-      for (int i = k - N + 1; i < N; ++i) acc += (int64_t)m[i] * (int64_t)C::MOD.v[k - i];
+      for (int i = k - N + 1; i < N; ++i) F29_MAD_C(acc, m[i], C::MOD.v[k - i]);
       r.l[k - N] = (int32_t)((uint32_t)acc & f29::MASK);
       acc >>= 29;
     }
@@ -247,24 +268,24 @@ struct F29 {
     for (int k = 0; k < N; ++k) {
 #pragma unroll
       for (int i = 0; i <= k; ++i) {
-        acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
-        acc += (int64_t)c.l[i] * (int64_t)d.l[k - i];
+        F29_MAD(acc, a.l[i], b.l[k - i]);
+        F29_MAD(acc, c.l[i], d.l[k - i]);
       }
 #pragma unroll
-      for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * (int64_t)C::MOD.v[k - i];
+      for (int i = 0; i < k; ++i) F29_MAD_C(acc, m[i], C::MOD.v[k - i]);
       m[k] = (int32_t)(((uint32_t)acc * C::NINV) & f29::MASK);
-      acc += (int64_t)m[k] * (int64_t)C::MOD.v[0];
+      F29_MAD_C(acc, m[k], C::MOD.v[0]);
       acc >>= 29;
     }
 #pragma unroll
     for (int k = N; k < 2 * N - 1; ++k) {
 #pragma unroll
       for (int i = k - N + 1; i < N; ++i) {
-        acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
-        acc += (int64_t)c.l[i] * (int64_t)d.l[k - i];
+        F29_MAD(acc, a.l[i], b.l[k - i]);
+        F29_MAD(acc, c.l[i], d.l[k - i]);
       }
 #pragma unroll
-      for (int i = k - N + 1; i < N; ++i) acc += (int64_t)m[i] * (int64_t)C::MOD.v[k - i];
+      for (int i = k - N + 1; i < N; ++i) F29_MAD_C(acc, m[i], C::MOD.v[k - i]);
       r.l[k - N] = (int32_t)((uint32_t)acc & f29::MASK);
       acc >>= 29;
     }
@@ -294,17 +315,17 @@ struct F29 {
 #pragma unroll
       for (int i = lo; i <= hi; ++i) {
         const int j = k - i;
-        if (i < j) acc += (int64_t)l[i] * (int64_t)d[j];
-        else if (i == j) acc += (int64_t)l[i] * (int64_t)l[i];
+        if (i < j) F29_MAD(acc, l[i], d[j]);
+        else if (i == j) F29_MAD(acc, l[i], l[i]);
       }
       if (k < N) {
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * (int64_t)C::MOD.v[k - i];
+        for (int i = 0; i < k; ++i) F29_MAD_C(acc, m[i], C::MOD.v[k - i]);
         m[k] = (int32_t)(((uint32_t)acc * C::NINV) & f29::MASK);
-        acc += (int64_t)m[k] * (int64_t)C::MOD.v[0];
+        F29_MAD_C(acc, m[k], C::MOD.v[0]);
       } else {
 #pragma unroll
-        for (int i = k - N + 1; i < N; ++i) acc += (int64_t)m[i] * (int64_t)C::MOD.v[k - i];
+        for (int i = k - N + 1; i < N; ++i) F29_MAD_C(acc, m[i], C::MOD.v[k - i]);
         r.l[k - N] = (int32_t)((uint32_t)acc & f29::MASK);
       }
       acc >>= 29;

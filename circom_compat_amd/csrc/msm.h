@@ -99,7 +99,11 @@ inline uint32_t msm_red_chunk(const MsmConfig& cfg, uint32_t nbatch = 1, uint32_
   // 7.11 / 7.44, 2^18 4.51 / 4.50 / 4.61 -- the narrower launch takes fewer issue slots from the accumulation it
   // hides under and still finishes before it.  Exposed reductions keep 65536 (2^22: 35.45 ms; 131072: 36.18;
   // 32768: 36.90).
-  const uint32_t target = hidden ? 32768u : 65536u;
+  // Only for SMALL bucket sets (<= 2^17 buckets per launch and rank): with more, half the threads means chains of
+  // 16 buckets and the reductions outlast what they hide under (one rank of 2 at 2^22: 20.4 -> 21.3 ms; one
+  // bucket-sharded rank of 8 at 2^24: 21.1 -> 23.8 ms, profiles/r06_proj_k22.json / _k24.json first runs).
+  const uint64_t per_launch = (uint64_t)nbatch * cfg.D * cfg.B / (world ? world : 1);
+  const uint32_t target = (hidden && per_launch <= (1u << 17)) ? 32768u : 65536u;
   uint32_t ch = (uint32_t)(((uint64_t)nbatch * cfg.D * cfg.B) / ((uint64_t)target * (world ? world : 1)));
   if (ch < 1) ch = 1;
   if (ch > (uint32_t)MSM_RED_CHUNK) ch = (uint32_t)MSM_RED_CHUNK;
