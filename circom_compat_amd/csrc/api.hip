@@ -322,7 +322,9 @@ void run_msms(g16_ctx* c, const Fr* w_dev, Hook after_ab, Hook2 after_b2) {
   // accumulations and costs them more than the earlier start returns (2^19 6.6 / 6.9, 2^20 11.2 / 11.4, Poseidon
   // 2^20 10.9 / 11.2 ms).
   const uint32_t nb_eff = c->cfg_w.nb() / (c->shard_buckets ? (uint32_t)c->world : 1u);
-  const bool sort_first = !sched_r5() && c->overlap && c->world == 1 && nb_eff >= (1u << 18);
+  // Up to 2^24: above, the witness map is what the H MSM waits for and must not start later
+  // (2^25: 265.3 ms map first, 267.8 sort first; 2^23 / 2^24 equal: profiles/r06_schedule_ab.txt block 5).
+  const bool sort_first = !sched_r5() && c->overlap && c->world == 1 && nb_eff >= (1u << 18) && c->n <= (1u << 24);
   if (sort_first) enqueue_witness_sort(c, w_dev);
   G16_HIP(hipEventRecord(c->ev_w, s));  // w is resident (upload enqueued on the main stream) [and sorted]
   G16_HIP(hipStreamWaitEvent(x, c->ev_w, 0));

@@ -20,9 +20,10 @@
 // again (the reference skips the multiplication for it, qap.rs via evaluate_constraint; here it
 // also skips the 32-byte load); any other coefficient becomes coeff * 2^266 mod r, canonical, in
 // the 8 words of the Fr, so that  mul(cooked, w_mont256) = coeff * w * 2^261  is the product in the
-// internal form with no conversion of the gathered witness value.  Unit-coefficient terms are
-// summed as raw Montgomery-256 integers and converted once per lane.  The result of a row is the
-// field element sum coeff * w[idx] -- identical to the reference's whatever the summation order.
+// internal form with no conversion of the gathered witness value; a unit coefficient is the constant 2^266 mod r.
+// Terms go through the reduction TWO at a time (mul2: (k1 w1 + k2 w2) / 2^261, 243 multiply-adds for two terms).
+// The result of a row is the field element sum coeff * w[idx] -- identical to the reference's whatever the
+// summation order.
 #pragma once
 #include <functional>
 
@@ -34,11 +35,10 @@ namespace g16 {
 constexpr uint32_t SPMV_ONE = 0x80000000u;  // col bit 31: coefficient == 1
 constexpr uint32_t SPMV_SHORT = 4;
 constexpr int SPMV_G = 4;
-// terms a lane sums lazily before its one reduction: 16 products in (-r, 2r) and 16 witness words
-// below 2^256 < 5.3 r keep  |S1| * 1 + |S0| * 1 < 32 + 85 < 169 r^2  (field29.h mul2 contract) even
-// for a witness that is not canonical.  SPMV_G = 4 lanes: a row's value stays below 2 G r = 8 r, so two
-// rows multiply (c = a b) without another reduction; measured on the 2^20 Poseidon chain (9.3 / 17.7
-// terms per A / B row): 8 lanes 0.65 ms, most of it the per-lane closing products of idle lanes
+// terms a lane sums lazily: 8 pair products in (-r, 2r) = |value| < 16 r; a pair's operands -- cooked coefficient
+// < r, witness word < 2^256 < 5.3 r even when it is not canonical -- keep |k1 w1| + |k2 w2| < 11 r^2 (field29.h mul2
+// contract: 169).  SPMV_G = 4 lanes (measured on the 2^20 Poseidon chain, 9.3 / 17.7 terms per A / B row: 8 lanes
+// 0.65 ms, most of it idle lanes; 4 lanes 0.58; rows sorted by trip count 0.51; pairs through mul2: see DESIGN.md)
 constexpr uint32_t SPMV_LANE_TERMS = 16;
 constexpr uint32_t SPMV_TASK_TERMS = SPMV_G * SPMV_LANE_TERMS;  // 64
 
@@ -75,41 +75,48 @@ void spmv_cook(uint32_t* col_dev, Fr* val_dev, size_t nnz, hipStream_t stream);
 // ---- device side --------------------------------------------------------------------------------
 #if defined(__HIPCC__) || defined(G16_EMU)
 
-struct SpmvLaneSum {
-  Fr29 s1;  // sum of cooked * w products (internal form)
-  Fr29 s0;  // sum of the unit-coefficient terms' witness words (Montgomery-256 integers)
+// One term as a pair of product operands: the cooked coefficient (c * 2^266; a unit coefficient is the constant
+// 2^266 mod r and costs no load) and the gathered witness word as a raw Montgomery-256 integer.
+struct SpmvTerm {
+  Fr29 k, w;
 };
-
-// terms s + lane, s + lane + stride, ... < e (at most SPMV_LANE_TERMS of them)
-__device__ __forceinline__ SpmvLaneSum spmv_lane_terms(const uint32_t* __restrict__ col,
-                                                       const Fr* __restrict__ val,
-                                                       const Fr* __restrict__ x, uint32_t s, uint32_t e,
-                                                       uint32_t lane, uint32_t stride) {
-  SpmvLaneSum r{Fr29::zero(), Fr29::zero()};
-  uint32_t j = s + lane;
-  uint32_t cj = j < e ? col[j] : 0u;
-  while (j < e) {
-    // the next term's column index is in flight while this term's witness word and coefficient arrive
-    const uint32_t jn = j + stride;
-    const uint32_t cn = jn < e ? col[jn] : 0u;
-    const Fr29 w = Fr29::unpack(x[cj & ~SPMV_ONE].v);
-    if (cj & SPMV_ONE) {
-      r.s0 = (r.s0 + w).carry();
-    } else {
-      r.s1 = (r.s1 + Fr29::unpack(val[j].v) * w).carry();
-    }
-    j = jn;
-    cj = cn;
+__device__ __forceinline__ SpmvTerm spmv_term(const Fr* __restrict__ val, const Fr* __restrict__ x, uint32_t j,
+                                              uint32_t cj, bool live) {
+  SpmvTerm t{Fr29::zero(), Fr29::zero()};
+  if (live) {
+    t.w = Fr29::unpack(x[cj & ~SPMV_ONE].v);
+    if (cj & SPMV_ONE) t.k = Fr29::from_limbs(Fr29::C::C266);
+    else t.k = Fr29::unpack(val[j].v);
   }
-  return r;
+  return t;
 }
-// the lane's sum in the internal form, product class: s1 + s0 * 2^5 with ONE reduction
-__device__ __forceinline__ Fr29 spmv_lane_close(const SpmvLaneSum& t) {
-  return Fr29::mul2(t.s1, Fr29::one(), t.s0, Fr29::from_limbs(Fr29::C::C266));
+
+// terms s + lane, s + lane + stride, ... < e (at most SPMV_LANE_TERMS of them), TWO per reduction:
+// (k1 w1 + k2 w2) / 2^261 is one mul2 (243 multiply-adds against 2 x 164 + a second set of column carries); a
+// missing second term is a pair of zeros.  Returns the lazy sum: carried limbs, |value| < 2 r per pair, i.e.
+// < SPMV_LANE_TERMS r.
+__device__ __forceinline__ Fr29 spmv_lane_terms(const uint32_t* __restrict__ col, const Fr* __restrict__ val,
+                                                const Fr* __restrict__ x, uint32_t s, uint32_t e, uint32_t lane,
+                                                uint32_t stride) {
+  Fr29 acc = Fr29::zero();
+  uint32_t j = s + lane;
+  // the next pair's column indices are in flight while this pair's witness words and coefficients arrive
+  uint32_t c1 = j < e ? col[j] : 0u, c2 = j + stride < e ? col[j + stride] : 0u;
+  while (j < e) {
+    const uint32_t j2 = j + stride, jn = j2 + stride, jn2 = jn + stride;
+    const uint32_t n1 = jn < e ? col[jn] : 0u, n2 = jn2 < e ? col[jn2] : 0u;
+    const SpmvTerm a = spmv_term(val, x, j, c1, true);
+    const SpmvTerm b = spmv_term(val, x, j2, c2, j2 < e);
+    acc = (acc + Fr29::mul2(a.k, a.w, b.k, b.w)).carry();
+    j = jn;
+    c1 = n1;
+    c2 = n2;
+  }
+  return acc;
 }
-// one thread, one short row (<= SPMV_LANE_TERMS terms): product class
+// one thread, one short row (<= SPMV_SHORT = 4 terms): carried limbs, |value| < 4 r
 __device__ __forceinline__ Fr29 spmv_row_thread(const SpmvDev& M, const Fr* __restrict__ x, uint32_t i) {
-  return spmv_lane_close(spmv_lane_terms(M.col, M.val, x, M.rowptr[i], M.rowptr[i + 1], 0u, 1u));
+  return spmv_lane_terms(M.col, M.val, x, M.rowptr[i], M.rowptr[i + 1], 0u, 1u);
 }
 __device__ __forceinline__ bool spmv_row_is_short(const SpmvDev& M, uint32_t i) {
   return M.rowptr[i + 1] - M.rowptr[i] <= SPMV_SHORT;
@@ -121,22 +128,22 @@ __device__ __forceinline__ Fr29 spmv_shfl_xor(const Fr29& a, int lane, int off) 
   for (int k = 0; k < f29::N; ++k) r.l[k] = (int32_t)__shfl((uint32_t)a.l[k], lane ^ off);
   return r;
 }
-// sum over the SPMV_G lanes of a group (every lane of the wave calls this): limbs carried, |value| < 2 G r
+// sum over the SPMV_G lanes of a group (every lane of the wave calls this): limbs carried, |value| < G x the lanes'
 __device__ __forceinline__ Fr29 spmv_group_sum(Fr29 t) {
   const int lane = (int)(threadIdx.x & 63u);
 #pragma unroll
   for (int off = SPMV_G / 2; off > 0; off >>= 1) t = (t + spmv_shfl_xor(t, lane, off)).carry();
   return t;
 }
-// terms [s, e), e - s <= SPMV_TASK_TERMS, by the lanes of one group: carried limbs, |value| < 2 G r
+// terms [s, e), e - s <= SPMV_TASK_TERMS, by the lanes of one group: carried limbs, |value| < G SPMV_LANE_TERMS r = 64 r
 __device__ __forceinline__ Fr29 spmv_group_terms(const SpmvDev& M, const Fr* __restrict__ x, uint32_t s,
                                                  uint32_t e) {
   const uint32_t gl = threadIdx.x & (uint32_t)(SPMV_G - 1);
-  return spmv_group_sum(spmv_lane_close(spmv_lane_terms(M.col, M.val, x, s, e, gl, (uint32_t)SPMV_G)));
+  return spmv_group_sum(spmv_lane_terms(M.col, M.val, x, s, e, gl, (uint32_t)SPMV_G));
 }
 
 // Out: struct with  __device__ void put(uint32_t row, const Fr29* v) const  -- v[q] = row of matrix q,
-// carried limbs (0..7 within [0, 2^29 + 2)), |value| < 8 r
+// carried limbs (0..7 within [0, 2^29 + 2)), |value| < 4 r
 template <int NM>
 struct SpmvMats {
   SpmvDev m[NM];
@@ -153,12 +160,12 @@ __global__ void __launch_bounds__(256) k_spmv_medium(SpmvMats<NM> M, const Fr* _
   Fr29 v[NM];
   auto row_of = [&](const SpmvDev& m) {
     const uint32_t s = live ? m.rowptr[i] : 0u, e = live ? m.rowptr[i + 1] : 0u;
-    return spmv_group_terms(m, x, s, e);  // |value| < 2 G r = 8 r, carried limbs: |a b| < 64 r^2 for put()
+    return spmv_group_terms(m, x, s, e) * Fr29::one();  // 64 r -> product class: |a b| < 4 r^2 for put()
   };
   v[0] = row_of(M.m[0]);  // written out: the unroller refuses a loop around the wave shuffles
   if constexpr (NM > 1) v[1] = row_of(M.m[1]);
   if constexpr (NM > 2) v[2] = row_of(M.m[2]);
-  static_assert(NM <= 3 && SPMV_G <= 4, "k_spmv_medium: at most three matrices; 2 G r must stay below 13 r");
+  static_assert(NM <= 3, "k_spmv_medium: at most three matrices");
   if (live && (threadIdx.x & (SPMV_G - 1)) == 0) out.put(i, v);
 }
 
@@ -175,7 +182,7 @@ __global__ void __launch_bounds__(256) k_spmv_tasks(SpmvMats<NM> M, const Fr* __
 #pragma unroll
   for (int k = 1; k < NM; ++k)
     if ((uint32_t)k == q) mq = M.m[k];
-  const Fr29 v = spmv_group_terms(mq, x, t.s, t.s + len);
+  const Fr29 v = spmv_group_terms(mq, x, t.s, t.s + len) * Fr29::one();  // 64 r -> product class (-r, 2 r)
   if (live && (threadIdx.x & (SPMV_G - 1)) == 0) {
 #pragma unroll
     for (int k = 0; k < f29::N; ++k) partial[(size_t)g * f29::N + k] = v.l[k];
@@ -198,8 +205,8 @@ __global__ void __launch_bounds__(64) k_spmv_huge(const uint32_t* __restrict__ h
       Fr29 p;
 #pragma unroll
       for (int l = 0; l < f29::N; ++l) p.l[l] = partial[(size_t)t * f29::N + l];
-      acc = (acc + p).carry();  // a partial is below 2 G r = 8 r
-      if (++pending == 16) {    // 2 r + 16 * 8 r = 130 r: back to the product class
+      acc = (acc + p).carry();  // a partial is in (-r, 2 r)
+      if (++pending == 64) {    // 2 r + 64 * 2 r = 130 r: back to the product class
         acc = acc * Fr29::one();
         pending = 0;
       }

@@ -72,7 +72,7 @@ echo "== 2. bench.py in-library, N = 1, 2, 4, 8"
 for N in 1 2 4 8; do
   [ "$N" -gt "$NDEV" ] && break
   if [ "$N" -eq 1 ]; then
-    python bench.py --gpus 1 --log2 $K --steps $STEPS --warmup 2 --cpu-log2 0 > $O/inlib_$N.json 2> $O/inlib_$N.err
+    python bench.py --gpus 1 --log2 $K --steps $STEPS --warmup 2 --cpu-log2 0 --no-pmc --no-secondary > $O/inlib_$N.json 2> $O/inlib_$N.err
   else
     G16_BENCH_MODE=inlib python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29600+N)) \
       bench.py --gpus $N --log2 $K --steps $STEPS --warmup 2 --cpu-log2 0 > $O/inlib_$N.json 2> $O/inlib_$N.err

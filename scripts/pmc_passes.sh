@@ -13,7 +13,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B" "TCC_EA0_WRREQ TCC_EA0_WRREQ_64B"; do
   i=$((i+1))
   G16_NO_OVERLAP=1 timeout 300 rocprofv3 --pmc $grp --kernel-include-regex "$RE" -f csv -d $ROOT/gpurun_out/$OUT/p$i -o p$i -- \
-      python $ROOT/bench.py --log2 $K --steps 1 --warmup 0 --cpu-log2 0 --no-pmc > $ROOT/gpurun_out/$OUT/p$i.log 2>&1
+      python $ROOT/bench.py --log2 $K --steps 1 --warmup 0 --cpu-log2 0 --no-pmc --no-secondary > $ROOT/gpurun_out/$OUT/p$i.log 2>&1
   echo "pass $i ($grp) rc=$?"
 done
 find $ROOT/gpurun_out/$OUT -name "*.csv" | head -20
