@@ -5,6 +5,7 @@
 # runs the emulator-backed tests against it.  ~25 min on 8 cores.  Usage: scripts/asan_emu.sh [pytest -k expr]
 set -e
 cd "$(dirname "$0")/.."; ROOT=$PWD
+mkdir -p build/asan
 make -C circom_compat_amd/csrc -j8 emu EMU_BUILD=../../build/emu_asan EMU_OUT=$ROOT/build/asan/libg16_emu.so \
   EMU_FLAGS="-O1 -g -std=c++17 -fPIC -DG16_EMU -include $ROOT/tests/emu/emu_hip.h -fsanitize=address -fno-omit-frame-pointer -Wno-unknown-pragmas" > build/asan_build.log 2>&1
 # libstdc++ is preloaded as well: python does not link it, and ASan's __cxa_throw interceptor aborts the

@@ -87,6 +87,15 @@ for N in 2 4 8; do
   echo "RCCL: $(grep -c 'Init COMPLETE' $O/ranks_$N.err) rank(s) report Init COMPLETE; $(grep -m1 -o 'nranks [0-9]*' $O/ranks_$N.err)"
   tail -1 $O/ranks_$N.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ranks N=%d' % d['n_gpus'], round(d['ms_per_step'],2), 'ms', d['parity'], d['config'].get('parallelism'))"
 done
+echo "== 3b. one process per GPU, RCCL issued by the LIBRARY (g16_dist_attach_rccl / g16_prove_dist), N = 2, 4, 8"
+# (rehearsal on one GPU: RCCL does not put two ranks on one device -- only the one-rank communicator runs there)
+if [ "$FAKE" = "1" ]; then LIST="1"; else LIST="2 4 8"; fi
+for N in $LIST; do
+  [ "$N" -gt "$NDEV" ] && break
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29800+N)) \
+    scripts/rccl_inlib_ranks.py $K $STEPS points > $O/rccl_inlib_$N.json 2> $O/rccl_inlib_$N.err
+  tail -1 $O/rccl_inlib_$N.json
+done
 echo "== 4. scaling table"
 python - $O <<'PY'
 import glob, json, os, sys
@@ -96,13 +105,13 @@ def ms(p):
     except Exception:
         return None
 t1 = ms(os.path.join(sys.argv[1], "inlib_1.json"))
-for mode in ("inlib", "ranks"):
+for mode in ("inlib", "ranks", "rccl_inlib"):
     for n in (2, 4, 8):
         t = ms(os.path.join(sys.argv[1], f"{mode}_{n}.json"))
         if t1 and t:
             print(f"{mode} N={n}: {t:.2f} ms, strong-scaling efficiency T1/(N T_N) = {t1 / (n * t):.3f}")
 try:
-    p = json.load(open("profiles/r05_proj_k24.json"))
+    p = json.load(open("profiles/r06_proj_k24.json"))
     for k, v in p["ranks"].items():
         print("one-GPU projection", k, round(v["efficiency_before_xgmi"], 3), "/ with all link time exposed", round(v["efficiency_if_all_link_time_exposed"], 3))
 except Exception as e:
