@@ -62,7 +62,7 @@ def test_clock_sampler_never_fails_without_a_device(monkeypatch):
     time.sleep(0.05)
     s.mark("after")
     s.stop()
-    assert time.time() - t0 < 5.0
+    assert time.time() - t0 < 60.0      # "does not hang": a loaded box (or the first HIP runtime probe) may take seconds
     out = s.summary()
     assert set(out) >= {"source", "timed", "after"}
     for label in ("timed", "after"):
