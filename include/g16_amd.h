@@ -312,8 +312,10 @@ g16_status g16_verify_batch(int device, const g16_vk_desc* vk, const uint8_t* pr
 /* A host that is not PyTorch (the Rust shim) creates one per-rank ctx per process (g16_options.rank / world,
  * dist_wm = 1) and ONE ncclComm_t over the same ranks with its own RCCL (ncclGetUniqueId / ncclCommInitRank),
  * then hands it over: nccl_comm is that opaque handle.  The library resolves ncclAllToAll / ncclAllGather /
- * ncclCommCount from the RCCL already loaded in the process (dlsym), else from librccl.so -- it does not link
- * RCCL -- checks that the communicator has g16_options.world ranks, allocates the two exchange buffers and a
+ * ncclCommCount from the RCCL already loaded in the process (dlsym(RTLD_DEFAULT)), else from librccl.so -- it does
+ * not link RCCL.  The collectives MUST run in the same RCCL copy that created the communicator: a host that links
+ * RCCL has it in the global symbol scope; a host that dlopen()s it (Python's ctypes) must open it with RTLD_GLOBAL
+ * (tests/test_gpu_large.py, scripts/rccl_inlib_ranks.py do).  The library checks that the communicator has g16_options.world ranks, allocates the two exchange buffers and a
  * high-priority exchange stream.  Afterwards g16_prove_dist is one whole sharded proof per rank:
  *   phase 1 -> ncclAllToAll -> phase 2 -> ncclAllToAll -> phase 3 -> ncclAllGather of the 1 KiB records -> finish
  * (the g16_prove_dist_phase* calls with the collectives in between, ordered by events: the host never blocks
