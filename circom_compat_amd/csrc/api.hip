@@ -420,8 +420,12 @@ static void enqueue_prove_tables(g16_ctx* c, const Fr* w_dev) {
 
 // after the main stream is synchronised: the proof bytes of the last enqueue_prove
 static void proof_from_pin(g16_ctx* c, uint8_t* proof_out) {
-  if (c->tbl.active) fin_tab_host_affine(c->pin_io + 64 + G16_PROOF_BYTES, proof_out);
-  else memcpy(proof_out, c->pin_io + 64, G16_PROOF_BYTES);
+  if (c->tbl.active) {
+    fin_tab_host_affine(c->pin_io + 64 + G16_PROOF_BYTES, proof_out);
+  } else {
+    memcpy(proof_out, c->pin_io + 64, G16_PROOF_BYTES);  // A and B were converted on the device, off the critical path
+    fin_host_affine_c(c->pin_io + 64 + G16_PROOF_BYTES, proof_out);  // C: the host divides (fin_final_proj)
+  }
 }
 
 // one whole single-device proof, enqueue only: (r, s) from and the proof to the ctx's pinned buffer
@@ -449,9 +453,12 @@ static void enqueue_prove(g16_ctx* c, const Fr* w_dev) {
       });
   G16_HIP(hipStreamWaitEvent(s, c->ev_side, 0));  // join
   int id = c->timer.enabled ? c->timer.begin(ST_FINALIZE, s) : -1;
-  fin_final(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->out_dev.p, s);
+  // C leaves the device in XYZZ form (the partial-record slot of out_dev is free on a world = 1 ctx): the host divides
+  fin_final_proj(c->key_dev.p, c->sums_dev.p, c->fin_scr.p, c->part_dev(), s);
   c->timer.end(id, s);
   G16_HIP(hipMemcpyAsync(c->pin_io + 64, c->out_dev.p, G16_PROOF_BYTES, hipMemcpyDeviceToHost, s));
+  G16_HIP(hipMemcpyAsync(c->pin_io + 64 + G16_PROOF_BYTES + FIN_PROJ_C, c->part_dev() + FIN_PROJ_C, sizeof(XYZZ<Fq>),
+                         hipMemcpyDeviceToHost, s));
 }
 
 // this rank's r*A-side products: s*A and r*B1 (variable-base, one wave each) overlap its L / B2 / H MSMs

@@ -58,6 +58,11 @@ void fin_b(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr
            hipStream_t stream);
 void fin_final(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr,
                uint8_t* proof_dev, hipStream_t stream);
+// fin_final with C left in XYZZ form at proj_dev + FIN_PROJ_C (below); fin_host_affine_c divides on the host and
+// writes proof[192, 256): the single-device prover's tail (g16_prove / g16_prove_dev)
+void fin_final_proj(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr, uint8_t* proj_dev,
+                    hipStream_t stream);
+void fin_host_affine_c(const uint8_t* proj_host, uint8_t* proof_out);
 
 // ---- sharded provers (one process per GPU) ----------------------------------------------------
 // The variable-base products of the finalisation are linear in the MSM sums, so every rank

@@ -258,6 +258,20 @@ __global__ void __launch_bounds__(64) k_fin_final(const KeyHeaderDev* key, const
   *reinterpret_cast<G1Affine*>(proof + 192) = to_storage_affine<Fq>(c);
 }
 
+// The same with C left in XYZZ form (storage Montgomery) at proj + FIN_PROJ_C: the one field inversion of the affine
+// conversion is 0.2 ms on one GPU lane -- on the critical path of EVERY proof, behind the last reduction -- and ~5 us
+// on the host, which waits for these bytes anyway (round 6; the table path has done so since round 5).
+__global__ void __launch_bounds__(64) k_fin_final_proj(const KeyHeaderDev* key, const ProofSums* sums,
+                                                       const FinScratch* scr, uint8_t* proj) {
+  if (threadIdx.x != 0) return;
+  G1XYZZ29 c = scr->sga;
+  c.add(scr->rgb);
+  c.add(scr->rsd1.neg());
+  c.add(sums->L);
+  c.add(sums->H);
+  *reinterpret_cast<XYZZ<Fq>*>(proj + FIN_PROJ_C) = xyzz_to_mont256<Fq>(c);
+}
+
 // g2_b -> B (needs only s * delta2 and the B2 sum: runs as soon as the B2 reduction is done,
 // underneath the H MSM)
 __global__ void __launch_bounds__(64) k_fin_b(const KeyHeaderDev* key, const ProofSums* sums,
@@ -498,6 +512,10 @@ void fin_final(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch*
                uint8_t* proof_dev, hipStream_t stream) {
   G16_LAUNCH(k_fin_final, 1, 64, 0, stream, key, sums, scr, proof_dev);
 }
+void fin_final_proj(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr, uint8_t* proj_dev,
+                    hipStream_t stream) {
+  G16_LAUNCH(k_fin_final_proj, 1, 64, 0, stream, key, sums, scr, proj_dev);
+}
 void fin_b(const KeyHeaderDev* key, const ProofSums* sums, const FinScratch* scr, uint8_t* proof_dev,
            hipStream_t stream) {
   G16_LAUNCH(k_fin_b, 1, 64, 0, stream, key, sums, scr, proof_dev);
@@ -612,6 +630,13 @@ void fin_tab_host_affine(const uint8_t* proj, uint8_t* proof) {
   const G2Affine pb = host_affine<Fq2>(b);
   memcpy(proof, (const void*)&pa, 64);
   memcpy(proof + 64, (const void*)&pb, 128);
+  memcpy(proof + 192, (const void*)&pc, 64);
+}
+
+void fin_host_affine_c(const uint8_t* proj, uint8_t* proof) {
+  XYZZ<Fq> c;
+  memcpy((void*)&c, proj + FIN_PROJ_C, sizeof c);
+  const G1Affine pc = host_affine<Fq>(c);
   memcpy(proof + 192, (const void*)&pc, 64);
 }
 
