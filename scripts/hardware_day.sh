@@ -10,8 +10,10 @@
 #   2. bench.py at N = 1, 2, 4, 8 in-library (one process, one host thread per device, peer copies)
 #   3. bench.py at N = 2, 4, 8 with one process per GPU (G16_BENCH_MODE=ranks: RCCL all_to_all /
 #      all_gather over xGMI on the registered exchange stream), RCCL's rank count printed
-#   4. the scaling table T1 / (N x T_N) for both, next to the one-GPU projection of
-#      profiles/r05_proj_k24.json
+#   3b. one process per GPU with the collectives issued by the LIBRARY (g16_dist_attach_rccl / g16_prove_dist,
+#      scripts/rccl_inlib_ranks.py), N = 2, 4, 8: every rank's proof == the single-GPU proof
+#   4. the scaling table T1 / (N x T_N) for all three, next to the one-GPU projection of
+#      profiles/r06_proj_k24.json
 set -u
 K=${1:-24}; STEPS=${2:-10}
 cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
