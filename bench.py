@@ -1210,6 +1210,11 @@ def main():
     cpu = None
     if args.cpu_log2 > 0:
         import cpu_ref
+        # the CPU restatement's thread pool follows what the host GRANTS (a cgroup quota below the visible CPU
+        # count throttles surplus threads): 2 x the granted cores, `cores` = the threads used, the grant beside it
+        # (cpu_ref.lib() does the sizing at load: G16_CPU_THREADS overrides)
+        granted, grant_how = cpu_ref.host_cpu_grant()
+        omp_default = cpu_ref.omp_default_threads()
 
         def cpu_prove(pk_c, mats_c, wc, reps):
             t_cpu, out = 0.0, None
@@ -1298,7 +1303,7 @@ def main():
         if cpu and n_gpus == 1:
             # the conservative column: the same proof with every MSM window cut into chunks of
             # bases so that windows x chunks tasks keep ALL host threads busy (g16cpu_set_msm_chunks) -- ark-ec's
-            # msm_bigint runs one rayon task per window (`value`), which leaves most of a 128-thread host idle
+            # msm_bigint runs one rayon task per window (`value`), which leaves most of a many-core host idle
             try:
                 T = cpu_ref.max_threads()
                 nw = ark_windows(max(m_prev, 2))
@@ -1348,7 +1353,8 @@ def main():
                                   "digit decomposition on all threads; C restatement of ark-groth16 0.5 prove() built with "
                                   + ("-O3 -mbmi2 -madx" if cpu_ref.variant() == "adx" else "-O3")
                                   + " (arkworks itself is not buildable offline)",
-                        "host_cpu_count": os.cpu_count()})
+                        "host_cpu_count": os.cpu_count(), "host_cpu_granted": granted,
+                        "host_cpu_grant": grant_how + f"; OpenMP's own default was {omp_default} threads"})
 
     # ---------------- roofline: the three instantiations of k_bucket_accumulate ----------------
     # A proof launches it four times: <Fq2, 1, false> for B2 (the longest launch of a step: the line's

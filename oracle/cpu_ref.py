@@ -36,8 +36,42 @@ def _cpu_has_adx_bmi2():
     return False
 
 
+def host_cpu_grant():
+    """Cores this process can really use: the affinity mask cut by the cgroup CPU quota (cgroup v2 cpu.max, v1
+    cfs_quota_us / cfs_period_us).  A gpurun box shows 256 logical CPUs and grants 16 (cpu.max = 1600000 100000,
+    `scripts/host_cores_probe.py`): threads beyond the quota are throttled, not run.  -> (cores, description)"""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    quota, how = None, "no cgroup CPU quota"
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota, how = float(q) / float(per), f"cgroup v2 cpu.max = {q} {per}"
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota, how = q / per, f"cgroup v1 cfs quota {q} / {per}"
+        except (OSError, ValueError):
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(quota + 0.999)))
+    return cores, f"{aff} CPUs in the affinity mask, {how}"
+
+
+_OMP_DEFAULT = None
+
+
+def omp_default_threads():
+    """OpenMP's own thread count before lib() cut it to the host's grant"""
+    lib()
+    return _OMP_DEFAULT
+
+
 def lib():
-    global _LIB, VARIANT
+    global _LIB, VARIANT, _OMP_DEFAULT
     if _LIB is None:
         VARIANT = "adx" if _cpu_has_adx_bmi2() and not os.environ.get("G16_CPU_BASELINE_ISA") else "baseline"
         name = "libg16_cpu_oracle_adx.so" if VARIANT == "adx" else "libg16_cpu_oracle.so"
@@ -47,6 +81,13 @@ def lib():
             subprocess.check_call(["make", "-C", _HERE])
         _LIB = C.CDLL(path)
         _LIB.g16cpu_max_threads.restype = C.c_int
+        # threads far beyond the cgroup CPU quota are throttled, not run: size the pool to TWICE what the host
+        # grants (not 1x: the window-parallel MSM has 15-19 tasks, and 17 tasks on 16 threads take two rounds --
+        # profiles/r06_cpu_threads_sweep.txt: 2^20 proof 5.1 s on 16 threads, 3.0-3.2 s on 24-64, 3.7 s on 128)
+        _OMP_DEFAULT = _LIB.g16cpu_max_threads()
+        want = int(os.environ.get("G16_CPU_THREADS", "0")) or min(_OMP_DEFAULT, 2 * host_cpu_grant()[0])
+        if want != _OMP_DEFAULT:
+            _LIB.g16cpu_set_threads(want)
     return _LIB
 
 
