@@ -36,23 +36,24 @@ def _cpu_has_adx_bmi2():
     return False
 
 
-def host_cpu_grant():
+def host_cpu_grant(root="/sys/fs/cgroup", aff=None):
     """Cores this process can really use: the affinity mask cut by the cgroup CPU quota (cgroup v2 cpu.max, v1
     cfs_quota_us / cfs_period_us).  A gpurun box shows 256 logical CPUs and grants 16 (cpu.max = 1600000 100000,
     `scripts/host_cores_probe.py`): threads beyond the quota are throttled, not run.  -> (cores, description)"""
-    try:
-        aff = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        aff = os.cpu_count() or 1
+    if aff is None:
+        try:
+            aff = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            aff = os.cpu_count() or 1
     quota, how = None, "no cgroup CPU quota"
     try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        q, per = open(os.path.join(root, "cpu.max")).read().split()[:2]
         if q != "max":
             quota, how = float(q) / float(per), f"cgroup v2 cpu.max = {q} {per}"
     except (OSError, ValueError):
         try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            q = int(open(os.path.join(root, "cpu", "cpu.cfs_quota_us")).read())
+            per = int(open(os.path.join(root, "cpu", "cpu.cfs_period_us")).read())
             if q > 0:
                 quota, how = q / per, f"cgroup v1 cfs quota {q} / {per}"
         except (OSError, ValueError):

@@ -369,3 +369,29 @@ def test_poseidon_reference_matches_circomlibjs_kats(emu):
     circ_bad = cc.CircomCircuit(type("R", (), dict(a=A, b=B, c=Cm, num_constraints=mats.num_constraints,
                                                    wire_mapping=None, num_inputs=2, num_variables=n_vars)), bad)
     assert circ_bad.first_unsatisfied(emu) >= 0
+
+
+def test_checker_thread_pool_follows_the_cgroup_cpu_grant(tmp_path):
+    """oracle/cpu_ref.py sizes the C restatement's OpenMP pool to the cores the host GRANTS: a gpurun box shows
+    256 logical CPUs under cgroup v2 cpu.max = 1600000 100000 (16 cores), and 128 throttled threads were slower
+    than 32 (profiles/r06_cpu_threads_sweep.txt).  The parser: v2 quota, v2 'max', v1 quota, v1 unlimited, nothing."""
+    import cpu_ref
+    v2 = tmp_path / "v2"
+    v2.mkdir()
+    (v2 / "cpu.max").write_text("1600000 100000\n")
+    assert cpu_ref.host_cpu_grant(str(v2), aff=256)[0] == 16
+    assert cpu_ref.host_cpu_grant(str(v2), aff=8)[0] == 8            # the affinity mask is the tighter bound
+    (v2 / "cpu.max").write_text("150000 100000\n")
+    assert cpu_ref.host_cpu_grant(str(v2), aff=256)[0] == 2          # 1.5 cores: rounded up
+    (v2 / "cpu.max").write_text("max 100000\n")
+    assert cpu_ref.host_cpu_grant(str(v2), aff=64) == (64, "64 CPUs in the affinity mask, no cgroup CPU quota")
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("400000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert cpu_ref.host_cpu_grant(str(v1), aff=64)[0] == 4
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert cpu_ref.host_cpu_grant(str(v1), aff=64)[0] == 64
+    assert cpu_ref.host_cpu_grant(str(tmp_path / "none"), aff=12)[0] == 12
+    # the loaded library: never more threads than OpenMP's own default, never fewer than one
+    assert 1 <= cpu_ref.max_threads() <= cpu_ref.omp_default_threads()
